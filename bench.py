@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of BASELINE.json: trajectory-steps per second (ODE steps/s x batch) of the batched
+probabilistic ODE solve, FitzHugh-Nagumo n_vars=2 q(n_deriv)=3, 4000 steps, `solve_mv` + `interrogate_kramer`,
+1024 trajectories per GPU (BASELINE.json configs[1]; SURVEY.md section 8d "C2").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete solve (forward filter kernel + backward smoother kernel) of this rank's batch with all
+inputs and outputs resident in HBM.  The path shards by independent trajectories: rank r owns global trajectories
+[r*B, (r+1)*B) ("weak" scaling, no data-path collective).  Timing: barrier + device sync on both sides of exactly K
+steps, MAX over ranks; rank 0 prints ONE JSON line.
+
+torch is used only as CPU-side rendezvous plumbing (gloo) when N > 1; it never touches the GPU.  The device work goes
+through librodeo_kalman.so (ctypes); barrier / max-reduce between ranks run over RCCL inside that library when the
+communicator comes up, else over gloo.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_STEPS, N_TRAJ, T_MAX, P, D = 4000, 1024, 40.0, 3, 2
+
+
+def make_problem(ra, rank):
+    """theta_b = (0.2,0.2,3) exp(0.1 eps_b), x0_b = (-1,1) + 0.1 eps'_b, seed 20240; global index."""
+    rng = np.random.default_rng(20240)
+    n_tot = N_TRAJ * (rank + 1)
+    eps = rng.standard_normal((n_tot, 5))[rank * N_TRAJ:(rank + 1) * N_TRAJ]
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.1 * eps[:, :3])
+    x0v = np.array([-1.0, 1.0]) + 0.1 * eps[:, 3:]
+    if rank == 0:
+        theta[0], x0v[0] = [0.2, 0.2, 3.0], [-1.0, 1.0]       # b = 0 is the unperturbed README problem
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, D, P)
+    x0 = init(x0v, 0.0, theta=theta)
+    prior = ra.ibm_init(T_MAX / N_STEPS, P, np.array([0.1, 0.1]))
+    return W, x0, theta, prior
+
+
+def cpu_baseline(W, x0, theta, prior):
+    """Plain-C restatement of the reference algorithm (oracle/c, 'port') on the host cores, bounded sample."""
+    try:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "c"), "native"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        from oracle import c_port
+        native = os.path.join(ROOT, "oracle", "c", "librk_oracle_native.so")
+        if os.path.exists(native):
+            c_port._PATH = native
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        # calibrate on a few trajectories, then size the sample for ~10-20 s of CPU work
+        t0 = time.perf_counter()
+        c_port.solve_mv("fitzhugh_nagumo", "kramer", W, x0[:cores], 0.0, T_MAX, N_STEPS, prior, theta[:cores], cores)
+        dt = max(time.perf_counter() - t0, 1e-3)
+        reps = int(min(max(12.0 / dt, 1), 64))
+        n = min(cores * reps, N_TRAJ)
+        t0 = time.perf_counter()
+        c_port.solve_mv("fitzhugh_nagumo", "kramer", W, x0[:n], 0.0, T_MAX, N_STEPS, prior, theta[:n], cores)
+        dt = time.perf_counter() - t0
+        return {"value": n * N_STEPS / dt, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
+                "sample": f"{n} of the {N_TRAJ} trajectories x {N_STEPS} steps, solve_mv+kramer, plain C -O3 "
+                          f"-march=native restatement of the reference algorithm, OpenMP over trajectories, {dt:.2f} s"}
+    except Exception as e:                                   # the baseline is a report, never a reason to fail
+        return {"value": None, "unit": "trajectory-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import rodeo_amd as ra                      # loads librodeo_kalman.so BEFORE torch's bundled ROCm libraries
+    from rodeo_amd import _lib
+    import ctypes as C
+    dev = ra.Device(local_rank)
+    lib = dev.lib
+
+    dist = None
+    comm = "none"
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = "gloo"
+        try:
+            uid = (C.c_char * _lib.COMM_UID_BYTES)()
+            if rank == 0:
+                _lib.check(lib.rk_comm_uid(uid))
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0)
+            uid = (C.c_char * _lib.COMM_UID_BYTES).from_buffer_copy(box[0])
+            _lib.check(lib.rk_comm_init(dev.h, rank, world, uid))
+            comm = "rccl"
+        except Exception as e:
+            print(f"[rank {rank}] RCCL communicator unavailable ({e}); using gloo for barriers", file=sys.stderr)
+
+    def barrier():
+        dev.sync()
+        if comm == "rccl":
+            _lib.check(lib.rk_comm_barrier(dev.h))
+        elif dist is not None:
+            dist.barrier()
+
+    W, x0, theta, prior = make_problem(ra, rank)
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, x0, 0.0, T_MAX, N_STEPS, ra.interrogate.interrogate_kramer, prior,
+                        device=dev, traj_offset=rank * N_TRAJ, theta=theta)
+    for _ in range(args.warmup):
+        plan.mv(None)
+    # ---- timed region: exactly K solves, inputs/outputs resident in HBM ----
+    barrier()
+    t0 = time.perf_counter()
+    dev.timer_start()
+    for _ in range(args.steps):
+        plan.mv(None)
+    dev_ms = dev.timer_stop()                  # HIP events on the library's stream (also synchronises)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # ---- per-kernel device time (HIP events around each launch), outside the timed region ----
+    dev.profile_enable(True)
+    acc = {}
+    reps = max(3, min(args.steps, 10))
+    for _ in range(reps):
+        plan.mv(None)
+        for name, ms in dev.profile_last():
+            acc.setdefault(name, []).append(ms)
+    dev.profile_enable(False)
+    kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
+
+    # sanity on the result of the timed computation (cheap): finite, end conditions
+    m_last = plan.mean_state.to_host()[-1]
+    ok = bool(np.all(np.isfinite(m_last)))
+
+    if rank == 0:
+        units = N_TRAJ * N_STEPS                                  # trajectory-steps per launch per rank
+        a_fwd, a_bwd = D * P * (P + 1) * 8, 2 * D * P * (P + 1) * 8    # write filt | read filt + write smooth
+        dom = max(kern_ms, key=kern_ms.get)
+        a_dom = a_fwd if dom.startswith("fwd") else a_bwd
+        achieved = a_dom * units / (kern_ms[dom] * 1e-3) / 1e9
+        solve_ms = sum(kern_ms.values())
+        out = {
+            "metric": "ODE steps/sec x batch (trajectory-steps/s), FitzHugh-Nagumo q=3, 4000 steps, solve_mv",
+            "value": world * units * args.steps / wall,
+            "unit": "trajectory-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: FitzHugh-Nagumo n_vars=2 n_deriv=3, t in [0,40], 4000 steps, "
+                                   "1024 trajectories per GPU (perturbed theta/x0, IBM prior sigma=0.1), "
+                                   "solve_mv + interrogate_kramer, kalman_type=standard",
+                       "n_traj_per_gpu": N_TRAJ, "n_steps": N_STEPS, "n_block": D, "n_bstate": P,
+                       "sharding": f"batch split over {world} rank(s), no data-path collective", "comm": comm,
+                       "result_finite": ok},
+            "device_ms_per_step": dev_ms / args.steps,
+            "kernels_ms": kern_ms,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_traj_step": a_dom},
+            "roofline_solve": {"bound": "hbm", "achieved": (a_fwd + a_bwd) * units / (solve_ms * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": (a_fwd + a_bwd) * units / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_traj_step": a_fwd + a_bwd},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, x0, theta, prior)
+        print(json.dumps(out), flush=True)
+
+    if comm == "rccl":
+        lib.rk_comm_destroy(dev.h)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,234 @@
+/*
+ * rodeo_kalman.h -- C ABI of librodeo_kalman.so: MI355X (gfx950) implementation of rodeo's Kalman
+ * filter / smoother time-stepping core, batched over independent trajectories.
+ *
+ * The reference (mlysy/rodeo v1.1.3) has no FFI: its boundaries are Python call conventions.  Each entry point
+ * below cites the reference function whose work it performs (paths relative to the reference tree); the Python
+ * package rodeo_amd/ binds these with ctypes and re-exposes rodeo's own names and keyword arguments
+ * (INTEGRATION.md shows the binding).  Plain pointers and sizes only -- no torch / JAX types.
+ *
+ * Conventions
+ * -----------
+ *  - Every function returns an int status: RK_OK (0) or a negative RK_ERR_* code; rk_last_error() returns a
+ *    thread-local message for the last failure.  The library never aborts.  Non-finite values propagate
+ *    silently, as in the reference (no NaN checks anywhere in src/rodeo/).
+ *  - The caller owns every buffer.  Device buffers come from rk_alloc / go to rk_free; the library keeps no
+ *    pointer between calls.
+ *  - One handle <-> one HIP device + one stream.  Calls on a handle are asynchronous w.r.t. the host unless
+ *    stated otherwise; rk_sync(h) waits.  Calls on one handle must be serialised by the caller.
+ *  - All arithmetic is IEEE fp64.
+ *
+ * Device data layout ("batch-minor")
+ * ----------------------------------
+ *  A per-trajectory array of logical shape S (e.g. (n_block, n_bstate, n_bstate)) for a batch of B trajectories
+ *  is stored as the array of shape (S..., B): the element e of trajectory b sits at  ptr[e * B + b].
+ *  Consecutive lanes of a wavefront therefore touch consecutive 8-byte words (512 B per wave per element).
+ *  Time-indexed outputs have shape (n_steps + 1, S..., B).  Inputs flagged "shared" (batched == 0) have plain
+ *  shape S and are broadcast to all trajectories.
+ */
+#ifndef RODEO_KALMAN_H
+#define RODEO_KALMAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------------------- */
+#define RK_OK                 0
+#define RK_ERR_INVALID       -1   /* null pointer / bad shape / inconsistent arguments                      */
+#define RK_ERR_UNSUPPORTED   -2   /* combination of (rhs, n_block, n_bstate, n_bmeas, interrogate, kalman)  */
+#define RK_ERR_HIP           -3   /* a HIP runtime call failed                                              */
+#define RK_ERR_RCCL          -4   /* an RCCL call failed                                                    */
+#define RK_ERR_NOMEM         -5
+
+/* ---- enumerations ------------------------------------------------------------------------------------- */
+/* kalman_type string of src/rodeo/solve.py:138-143 */
+#define RK_KALMAN_STANDARD    0   /* "standard"    -> src/rodeo/kalmantv/standard.py    */
+#define RK_KALMAN_SQRT        1   /* "square-root" -> src/rodeo/kalmantv/square_root.py */
+
+/* interrogate callable of src/rodeo/solve.py:70-78, recognised by identity on the Python side */
+#define RK_INTERROGATE_RODEO      0   /* src/rodeo/interrogate.py:87-115 */
+#define RK_INTERROGATE_SCHOBER    1   /* src/rodeo/interrogate.py:50-62  */
+#define RK_INTERROGATE_KRAMER     2   /* src/rodeo/interrogate.py:65-84  */
+#define RK_INTERROGATE_CHKREBTII  3   /* src/rodeo/interrogate.py:13-47  */
+
+/* built-in ODE right-hand sides (device code for the `ode_fun` callable of src/rodeo/solve.py:218) */
+#define RK_RHS_FITZHUGH_NAGUMO  1   /* README.md:92-99; theta = (a, b, c); n_block = 2, n_bmeas = 1           */
+#define RK_RHS_LORENZ63         2   /* docs/examples/lorenz.md:85-92; theta = (rho, sigma, beta); n_block = 3 */
+#define RK_RHS_HIGHER_ORDER     3   /* docs/examples/higher_order.md:47-59; x'' = sin 2t - x; n_block = 1     */
+#define RK_RHS_LINEAR_DENSE     4   /* x' = A x as one dense block (prior/indep_init.py); theta = A row-major */
+
+/* flags for rk_solve_cfg.flags */
+#define RK_FLAG_STORE_PRED   1    /* also write the predicted moments (solve.py:93-96 state_pred)            */
+
+typedef struct rk_handle_s* rk_handle;
+
+/* ---- handle, memory, synchronisation ------------------------------------------------------------------ */
+int         rk_create(int device_id, rk_handle* h);
+int         rk_destroy(rk_handle h);
+const char* rk_last_error(void);
+const char* rk_version(void);
+int         rk_device_count(int* n);
+int         rk_device_name(rk_handle h, char* buf, size_t buflen);
+int         rk_alloc(rk_handle h, size_t bytes, void** dptr);
+int         rk_free(rk_handle h, void* dptr);
+int         rk_memset(rk_handle h, void* dptr, int value, size_t bytes);
+int         rk_h2d(rk_handle h, void* dst_dev, const void* src_host, size_t bytes);   /* synchronous */
+int         rk_d2h(rk_handle h, void* dst_host, const void* src_dev, size_t bytes);   /* synchronous */
+int         rk_sync(rk_handle h);
+
+/* HIP-event timing on the handle's stream (the stream every kernel of this library is launched on). */
+int         rk_timer_start(rk_handle h);
+int         rk_timer_stop(rk_handle h, double* elapsed_ms);     /* records, synchronises, returns elapsed   */
+/* Per-kernel device time of the last rk_solve_* call on this handle, from HIP events bracketing each launch.
+ * Enabled with rk_profile_enable(h, 1); names/ms arrays of capacity cap are filled, *n = number of launches. */
+int         rk_profile_enable(rk_handle h, int on);
+int         rk_profile_last(rk_handle h, int cap, const char** names, double* ms, int* n);
+
+/* ---- whole-solve boundary ---------------------------------------------------------------------------------
+ * Mirrors  solve_mv / solve_sim (key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate,
+ *                                prior_pars, kalman_type, **params)         src/rodeo/solve.py:125-129,208-212 */
+typedef struct {
+    int32_t  n_traj;        /* B: trajectories held by THIS handle/rank                                     */
+    int32_t  n_steps;       /* N (solve.py:223)                                                             */
+    int32_t  n_block;       /* d = ode_weight.shape[0]                                                      */
+    int32_t  n_bstate;      /* p = ode_weight.shape[2]                                                      */
+    int32_t  n_bmeas;       /* m = ode_weight.shape[1]                                                      */
+    int32_t  rhs_id;        /* RK_RHS_*                                                                     */
+    int32_t  interrogate;   /* RK_INTERROGATE_*                                                             */
+    int32_t  kalman_type;   /* RK_KALMAN_*                                                                  */
+    int32_t  n_theta;       /* doubles of ODE parameters per trajectory                                     */
+    int32_t  flags;         /* RK_FLAG_*                                                                    */
+    double   t_min, t_max;  /* solve.py:221-222; step n is interrogated at t_min + (t_max-t_min)(n+1)/N     */
+    uint64_t seed;          /* Philox key (stands in for the jax PRNG `key`; see oracle/counter_rng.py)     */
+    uint64_t traj_offset;   /* global index of local trajectory 0: makes draws independent of the sharding  */
+} rk_solve_cfg;
+
+typedef struct {
+    const double* ode_weight;    int32_t ode_weight_batched;    /* W  (d, m, p [,B])   solve.py:219         */
+    const double* ode_init;      int32_t ode_init_batched;      /* x0 (d, p [,B])      solve.py:220         */
+    const double* prior_weight;  int32_t prior_weight_batched;  /* Q  (d, p, p [,B])   prior_pars[0]        */
+    const double* prior_var;     int32_t prior_var_batched;     /* R  (d, p, p [,B])   prior_pars[1]        */
+    const double* theta;         int32_t theta_batched;         /* (n_theta [,B])      **params, packed     */
+} rk_solve_in;
+
+typedef struct {
+    /* filtered moments; after rk_solve_mv they hold the SMOOTHED moments (smoothing is done in place)      */
+    double* mean_state;     /* (N+1, d, p, B)                                                               */
+    double* var_state;      /* (N+1, d, p, p, B)                                                            */
+    /* predicted moments, only written when RK_FLAG_STORE_PRED is set (may be NULL otherwise)               */
+    double* mean_pred;      /* (N+1, d, p, B)                                                               */
+    double* var_pred;       /* (N+1, d, p, p, B)                                                            */
+    /* rk_solve_sim: the sample path; mean_state / var_state are then the filter workspace                  */
+    double* x_state;        /* (N+1, d, p, B)                                                               */
+} rk_solve_out;
+
+/* bytes of the arrays above for a configuration (any pointer may be NULL) */
+int rk_solve_sizes(const rk_solve_cfg* cfg, size_t* mean_bytes, size_t* var_bytes);
+
+/* forward pass only: src/rodeo/solve.py:31-122 (_solve_filter).  out->mean_state/var_state <- filtered. */
+int rk_solve_filter(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out);
+/* forward + backward mean/variance smoother: src/rodeo/solve.py:208-302 (solve_mv).                     */
+int rk_solve_mv(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out);
+/* forward + backward sampler: src/rodeo/solve.py:125-205 (solve_sim).  out->x_state <- one draw per traj. */
+int rk_solve_sim(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out);
+
+/* Gather x[obs_ind[k], :, 0] and reduce the Gaussian observation log-likelihood + N(0, prior_sd^2) log-prior
+ * per trajectory: the tail of the user log-posterior of docs/examples/parameter.md:188-210,331-354 (and of
+ * src/rodeo/inference/basic.py:47-62 with a Gaussian obs_loglik).
+ *   x_state (N+1, d, p, B); obs (n_obs, d) host-layout on device; obs_ind (n_obs) int32 on device;
+ *   upars (n_prior, B) batch-minor or NULL (no prior term); out logpost (B).                              */
+int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n_block, int32_t n_bstate,
+                         const double* x_state, const double* obs, const int32_t* obs_ind, int32_t n_obs,
+                         double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
+                         double* logpost);
+
+/* ---- per-step operator boundary -------------------------------------------------------------------------
+ * Batched versions of the nine functions of src/rodeo/kalmantv/standard.py (kalman_type = RK_KALMAN_STANDARD)
+ * and src/rodeo/kalmantv/square_root.py (RK_KALMAN_SQRT).  n = batch size (the reference's vmap axis);
+ * every array is batch-minor: vectors (n_state, n), matrices (rows, cols, n).  A NULL optional input means 0.
+ * Names of the arguments are the reference's keyword names.                                                 */
+typedef struct {
+    int32_t n;            /* batch                                                                         */
+    int32_t n_state;
+    int32_t n_meas;
+    int32_t kalman_type;
+} rk_op_cfg;
+
+/* standard.py:31-60 / square_root.py:30-58 */
+int rk_kalman_predict_batched(rk_handle h, const rk_op_cfg* c,
+        const double* mean_state_past, const double* var_state_past, const double* mean_state,
+        const double* wgt_state, const double* var_state,
+        double* mean_state_pred, double* var_state_pred);
+/* standard.py:63-103 / square_root.py:61-101 */
+int rk_kalman_update_batched(rk_handle h, const rk_op_cfg* c,
+        const double* mean_state_pred, const double* var_state_pred, const double* x_meas,
+        const double* mean_meas, const double* wgt_meas, const double* var_meas,
+        double* mean_state_filt, double* var_state_filt);
+/* standard.py:106-157 / square_root.py:104-155 */
+int rk_kalman_filter_batched(rk_handle h, const rk_op_cfg* c,
+        const double* mean_state_past, const double* var_state_past, const double* mean_state,
+        const double* wgt_state, const double* var_state, const double* x_meas,
+        const double* mean_meas, const double* wgt_meas, const double* var_meas,
+        double* mean_state_pred, double* var_state_pred, double* mean_state_filt, double* var_state_filt);
+/* standard.py:180-217 / square_root.py:178-219 (var_state = R factor is required for RK_KALMAN_SQRT) */
+int rk_kalman_smooth_mv_batched(rk_handle h, const rk_op_cfg* c,
+        const double* mean_state_next, const double* var_state_next,
+        const double* mean_state_filt, const double* var_state_filt,
+        const double* mean_state_pred, const double* var_state_pred,
+        const double* wgt_state, const double* var_state,
+        double* mean_state_smooth, double* var_state_smooth);
+/* standard.py:220-255 / square_root.py:222-261 */
+int rk_kalman_smooth_sim_batched(rk_handle h, const rk_op_cfg* c,
+        const double* x_state_next,
+        const double* mean_state_filt, const double* var_state_filt,
+        const double* mean_state_pred, const double* var_state_pred,
+        const double* wgt_state, const double* var_state,
+        double* mean_state_sim, double* var_state_sim);
+/* standard.py:258-305 / square_root.py:264-314 */
+int rk_kalman_smooth_batched(rk_handle h, const rk_op_cfg* c,
+        const double* x_state_next, const double* mean_state_next, const double* var_state_next,
+        const double* mean_state_filt, const double* var_state_filt,
+        const double* mean_state_pred, const double* var_state_pred,
+        const double* wgt_state, const double* var_state,
+        double* mean_state_sim, double* var_state_sim, double* mean_state_smooth, double* var_state_smooth);
+/* standard.py:308-336 / square_root.py:317-345 */
+int rk_kalman_forecast_batched(rk_handle h, const rk_op_cfg* c,
+        const double* mean_state_pred, const double* var_state_pred,
+        const double* mean_meas, const double* wgt_meas, const double* var_meas,
+        double* mean_fore, double* var_fore);
+/* standard.py:339-371 / square_root.py:348-385 */
+int rk_kalman_smooth_cond_batched(rk_handle h, const rk_op_cfg* c,
+        const double* mean_state_filt, const double* var_state_filt,
+        const double* mean_state_pred, const double* var_state_pred,
+        const double* wgt_state, const double* var_state,
+        double* wgt_state_cond, double* mean_state_cond, double* var_state_cond);
+
+/* ---- interrogation boundary ------------------------------------------------------------------------------
+ * One interrogation for a batch of predicted states: src/rodeo/interrogate.py (all four variants; the variant,
+ * rhs, dims, seed and traj_offset are taken from cfg; `step` addresses the Philox stream for chkrebtii).
+ *   mean_state_pred (d, p, B), var_state_pred (d, p, p, B), ode_weight/theta as in rk_solve_in;
+ *   outputs wgt_meas (d, m, p, B), mean_meas (d, m, B), var_meas (d, m, m, B).                               */
+int rk_interrogate_batched(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, double t, int32_t step,
+        const double* mean_state_pred, const double* var_state_pred,
+        double* wgt_meas, double* mean_meas, double* var_meas);
+
+/* ---- multi-GPU: batch sharding over RCCL / xGMI --------------------------------------------------------------
+ * The path shards by independent trajectories (no data-path collective).  The only exchange is the all-gather of
+ * per-trajectory scalars (e.g. log-posteriors).  uid is an opaque 128-byte ncclUniqueId made on rank 0 and
+ * distributed by the host launcher.                                                                           */
+#define RK_COMM_UID_BYTES 128
+int rk_comm_uid(void* uid128);
+int rk_comm_init(rk_handle h, int rank, int nranks, const void* uid128);
+int rk_comm_destroy(rk_handle h);
+int rk_allgather_f64(rk_handle h, const double* send_dev, double* recv_dev, size_t count_per_rank);
+int rk_allreduce_max_f64(rk_handle h, const double* send_dev, double* recv_dev, size_t count);
+int rk_comm_barrier(rk_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RODEO_KALMAN_H */

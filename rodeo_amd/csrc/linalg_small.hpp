@@ -1,0 +1,143 @@
+// Register-resident small dense linear algebra for one (trajectory, block) per lane.
+// All loops are fully unrolled over compile-time sizes so every array lives in VGPRs (runtime-indexed arrays would
+// go to scratch).  Operation order follows the reference's expressions (src/rodeo/kalmantv/standard.py) so that the
+// rounding pattern stays as close to the JAX path as a different BLAS allows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rk {
+
+// C = A (RxK) * B (KxC)
+template <int R, int K, int C>
+__device__ __forceinline__ void mm(const double (&A)[R][K], const double (&B)[K][C], double (&out)[R][C]) {
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            double s = A[i][0] * B[0][j];
+#pragma unroll
+            for (int k = 1; k < K; ++k) s = fma(A[i][k], B[k][j], s);
+            out[i][j] = s;
+        }
+}
+
+// C = A (RxK) * B^T, B is (CxK)
+template <int R, int K, int C>
+__device__ __forceinline__ void mm_nt(const double (&A)[R][K], const double (&B)[C][K], double (&out)[R][C]) {
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            double s = A[i][0] * B[j][0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) s = fma(A[i][k], B[j][k], s);
+            out[i][j] = s;
+        }
+}
+
+// y = A (RxK) x
+template <int R, int K>
+__device__ __forceinline__ void mv(const double (&A)[R][K], const double (&x)[K], double (&y)[R]) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        double s = A[i][0] * x[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) s = fma(A[i][k], x[k], s);
+        y[i] = s;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ double dot(const double (&a)[K], const double (&b)[K]) {
+    double s = a[0] * b[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) s = fma(a[k], b[k], s);
+    return s;
+}
+
+// X = A^{-1} B by LU with partial pivoting (what jnp.linalg.solve does, src/rodeo/utils.py:119 -> LAPACK gesv:
+// first-maximum pivot search, right-looking elimination).  A (PxP) and B (PxNR) are destroyed; B <- X.
+// Row swaps are predicated selects so the arrays stay in registers.  A singular pivot yields inf/NaN, silently,
+// like the reference.
+template <int P, int NR>
+__device__ __forceinline__ void lu_solve(double (&A)[P][P], double (&B)[P][NR]) {
+    double rpiv[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        // pivot search in column k (first maximum of |a_ik|, i >= k)
+        int piv = k;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < P; ++i) {
+            const double v = fabs(A[i][k]);
+            const bool gt = v > best;
+            best = gt ? v : best;
+            piv = gt ? i : piv;
+        }
+#pragma unroll
+        for (int i = k + 1; i < P; ++i) {
+            const bool sw = (piv == i);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const double t = A[k][j];
+                A[k][j] = sw ? A[i][j] : t;
+                A[i][j] = sw ? t : A[i][j];
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const double t = B[k][j];
+                B[k][j] = sw ? B[i][j] : t;
+                B[i][j] = sw ? t : B[i][j];
+            }
+        }
+        rpiv[k] = 1.0 / A[k][k];
+#pragma unroll
+        for (int i = k + 1; i < P; ++i) {
+            const double l = A[i][k] * rpiv[k];
+#pragma unroll
+            for (int j = k + 1; j < P; ++j) A[i][j] = fma(-l, A[k][j], A[i][j]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) B[i][j] = fma(-l, B[k][j], B[i][j]);
+        }
+    }
+    // back substitution with the upper factor
+#pragma unroll
+    for (int k = P - 1; k >= 0; --k) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            double s = B[k][j];
+#pragma unroll
+            for (int i = k + 1; i < P; ++i) s = fma(-A[k][i], B[i][j], s);
+            B[k][j] = s * rpiv[k];
+        }
+    }
+}
+
+// Lower-triangular F with F F^T = A for symmetric positive semi-definite A (reads the lower triangle); a
+// non-positive pivot zeroes its column instead of producing NaN.  Mirror: oracle/interrogations.py psd_factor.
+template <int P>
+__device__ __forceinline__ void psd_factor(const double (&A)[P][P], double (&L)[P][P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j < P; ++j) L[i][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d = fma(-L[j][k], L[j][k], d);
+        const bool ok = d > 0.0;
+        const double dj = sqrt(ok ? d : 1.0);
+        const double rdj = 1.0 / dj;
+        L[j][j] = ok ? dj : 0.0;
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+            double s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = fma(-L[i][k], L[j][k], s);
+            L[i][j] = ok ? s * rdj : 0.0;
+        }
+    }
+}
+
+}  // namespace rk

@@ -1,0 +1,87 @@
+// Device code for the `ode_fun(X, t, **params)` callable of src/rodeo/solve.py:218 and for the block-diagonal of
+// its Jacobian that interrogate_kramer extracts from jax.jacfwd (src/rodeo/interrogate.py:76-79).
+//
+// A right-hand side is a struct with
+//   D       n_block,  NTHETA  number of packed parameters per trajectory  (n_bmeas = 1 for all of these)
+//   f   (X[D][P], t, th[NTHETA], out[D])              out[b]    = f_b(X, t)
+//   fjac(X[D][P], t, th[NTHETA], out[D], J[D][P])     J[b][j]   = d f_b / d X[b][j]   (off-block terms dropped,
+//                                                                  interrogate.py:70)
+// NumPy mirrors used by the tests: oracle/odes.py.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rk {
+
+// FitzHugh-Nagumo, README.md:92-99 / docs/examples/parameter.md:60-68.  theta = (a, b, c).
+struct FitzHughNagumo {
+    static constexpr int D = 2;
+    static constexpr int NTHETA = 3;
+    template <int P>
+    __device__ __forceinline__ static void f(const double (&X)[D][P], double, const double (&th)[NTHETA],
+                                             double (&out)[D]) {
+        const double a = th[0], b = th[1], c = th[2];
+        const double V = X[0][0], R = X[1][0];
+        out[0] = c * (V - V * V * V / 3 + R);
+        out[1] = -1 / c * (V - a + b * R);
+    }
+    template <int P>
+    __device__ __forceinline__ static void fjac(const double (&X)[D][P], double t, const double (&th)[NTHETA],
+                                                double (&out)[D], double (&J)[D][P]) {
+        f<P>(X, t, th, out);
+#pragma unroll
+        for (int b = 0; b < D; ++b)
+#pragma unroll
+            for (int j = 0; j < P; ++j) J[b][j] = 0.0;
+        const double V = X[0][0];
+        J[0][0] = th[2] * (1.0 - V * V);
+        J[1][0] = -th[1] / th[2];
+    }
+};
+
+// Lorenz63, docs/examples/lorenz.md:85-92.  theta = (rho, sigma, beta).
+struct Lorenz63 {
+    static constexpr int D = 3;
+    static constexpr int NTHETA = 3;
+    template <int P>
+    __device__ __forceinline__ static void f(const double (&X)[D][P], double, const double (&th)[NTHETA],
+                                             double (&out)[D]) {
+        const double rho = th[0], sigma = th[1], beta = th[2];
+        const double x = X[0][0], y = X[1][0], z = X[2][0];
+        out[0] = -sigma * x + sigma * y;
+        out[1] = rho * x - y - x * z;
+        out[2] = -beta * z + x * y;
+    }
+    template <int P>
+    __device__ __forceinline__ static void fjac(const double (&X)[D][P], double t, const double (&th)[NTHETA],
+                                                double (&out)[D], double (&J)[D][P]) {
+        f<P>(X, t, th, out);
+#pragma unroll
+        for (int b = 0; b < D; ++b)
+#pragma unroll
+            for (int j = 0; j < P; ++j) J[b][j] = 0.0;
+        J[0][0] = -th[1];
+        J[1][0] = -1.0;
+        J[2][0] = -th[2];
+    }
+};
+
+// Second-order ODE of Chkrebtii et al, docs/examples/higher_order.md:47-59:  x'' = sin(2t) - x.
+struct HigherOrder {
+    static constexpr int D = 1;
+    static constexpr int NTHETA = 1;   // unused (one dummy slot keeps the array types non-empty)
+    template <int P>
+    __device__ __forceinline__ static void f(const double (&X)[D][P], double t, const double (&)[NTHETA],
+                                             double (&out)[D]) {
+        out[0] = sin(2 * t) - X[0][0];
+    }
+    template <int P>
+    __device__ __forceinline__ static void fjac(const double (&X)[D][P], double t, const double (&th)[NTHETA],
+                                                double (&out)[D], double (&J)[D][P]) {
+        f<P>(X, t, th, out);
+#pragma unroll
+        for (int j = 0; j < P; ++j) J[0][j] = 0.0;
+        J[0][0] = -1.0;
+    }
+};
+
+}  // namespace rk

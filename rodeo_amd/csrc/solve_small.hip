@@ -1,0 +1,568 @@
+// Small-block solver kernels (n_bmeas = 1, n_bstate <= 6): the fused time loops of
+//   src/rodeo/solve.py:31-122   _solve_filter   -> fwd_kernel
+//   src/rodeo/solve.py:257-301  solve_mv        -> bwd_mv_kernel   (in place over the filtered moments)
+//   src/rodeo/solve.py:162-204  solve_sim       -> bwd_sim_kernel
+// The whole N-step recursion of a trajectory runs inside ONE kernel launch; the state lives in VGPRs and only the
+// filtered / smoothed moments touch HBM, in the batch-minor layout of include/rodeo_kalman.h (512 B per wave per
+// element row).  Predicted moments are re-evaluated from the filtered ones in the backward pass instead of being
+// stored (they are a pure function of filt[n], Q, R: standard.py:57-59).
+#include "common.hpp"
+#include "kalman_small.hpp"
+#include "philox.hpp"
+#include "rhs.hpp"
+
+namespace rk {
+
+struct SolveArgs {
+    int B, N, D;
+    double t_min, t_max;
+    uint64_t seed, traj_offset;
+    const double *W, *x0, *Q, *R, *theta;
+    int W_b, x0_b, Q_b, R_b, theta_b;
+    double *mean, *var, *mean_pred, *var_pred, *x;
+};
+
+__device__ __forceinline__ double ld(const double* p, size_t e, int batched, int B, int b) {
+    return batched ? p[e * (size_t)B + b] : p[e];
+}
+
+template <int P>
+__device__ __forceinline__ void load_block_consts(const SolveArgs& a, int blk, int b, double (&Q)[P][P],
+                                                  double (&R)[P][P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const size_t e = ((size_t)blk * P + i) * P + j;
+            Q[i][j] = ld(a.Q, e, a.Q_b, a.B, b);
+            R[i][j] = ld(a.R, e, a.R_b, a.B, b);
+        }
+}
+
+// ---- interrogation of one trajectory (all blocks): src/rodeo/interrogate.py -----------------------------------
+// Produces W_meas = ode_weight + wgt_meas (solve.py:79), mean_meas and var_meas (n_bmeas = 1 -> scalars per block).
+template <class RHS, int P, int ITG>
+__device__ __forceinline__ void interrogate_traj(const double (&W)[RHS::D][P], const double (&th)[RHS::NTHETA],
+                                                 double t, const double (&mup)[RHS::D][P],
+                                                 const double (&Sp)[RHS::D][P][P], uint64_t seed, uint32_t traj,
+                                                 uint32_t step, double (&wgt)[RHS::D][P], double (&a)[RHS::D],
+                                                 double (&V)[RHS::D]) {
+    constexpr int D = RHS::D;
+    double f[D];
+    if constexpr (ITG == RK_INTERROGATE_KRAMER) {
+        // interrogate.py:75-84: wgt_meas = -J ; mean_meas = -f + J mu- ; var_meas = 0
+        double J[D][P];
+        RHS::template fjac<P>(mup, t, th, f, J);
+#pragma unroll
+        for (int blk = 0; blk < D; ++blk) {
+            a[blk] = -f[blk] + dot<P>(J[blk], mup[blk]);
+            V[blk] = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) wgt[blk][j] = -J[blk][j];
+        }
+    } else {
+        if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
+            // interrogate.py:22-34,46: x_b ~ N(mu-_b, Sigma-_b) ; mean_meas = -f(x) ; var_meas = W Sigma- W^T
+            double xs[D][P];
+#pragma unroll
+            for (int blk = 0; blk < D; ++blk) {
+                double z[P];
+                normals<P>(seed, traj, step, (uint32_t)blk, PURPOSE_INTERROGATE, z);
+                mvn_draw<P>(mup[blk], Sp[blk], z, xs[blk]);
+            }
+            RHS::template f<P>(xs, t, th, f);
+        } else {
+            // interrogate.py:61 / :114: mean_meas = -f(mu-)
+            RHS::template f<P>(mup, t, th, f);
+        }
+#pragma unroll
+        for (int blk = 0; blk < D; ++blk) {
+            a[blk] = -f[blk];
+#pragma unroll
+            for (int j = 0; j < P; ++j) wgt[blk][j] = 0.0;
+            if constexpr (ITG == RK_INTERROGATE_SCHOBER) {
+                V[blk] = 0.0;                                     // interrogate.py:60
+            } else {
+                double WS[P];                                     // interrogate.py:110-113 / :26-29
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    double s = W[blk][0] * Sp[blk][0][j];
+#pragma unroll
+                    for (int i = 1; i < P; ++i) s = fma(W[blk][i], Sp[blk][i][j], s);
+                    WS[j] = s;
+                }
+                V[blk] = dot<P>(WS, W[blk]);
+            }
+        }
+    }
+}
+
+// ---- forward pass: one lane per trajectory -----------------------------------------------------------------------
+template <class RHS, int P, int ITG, bool STORE_PRED>
+__global__ void __launch_bounds__(64) fwd_kernel(SolveArgs a) {
+    constexpr int D = RHS::D;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const size_t B = (size_t)a.B;
+
+    double Q[D][P][P], R[D][P][P], W[D][P], th[RHS::NTHETA];
+#pragma unroll
+    for (int blk = 0; blk < D; ++blk) {
+        load_block_consts<P>(a, blk, b, Q[blk], R[blk]);
+#pragma unroll
+        for (int j = 0; j < P; ++j) W[blk][j] = ld(a.W, (size_t)blk * P + j, a.W_b, a.B, b);
+    }
+#pragma unroll
+    for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
+
+    double mu[D][P], S[D][P][P];
+#pragma unroll
+    for (int blk = 0; blk < D; ++blk)
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            mu[blk][i] = ld(a.x0, (size_t)blk * P + i, a.x0_b, a.B, b);
+#pragma unroll
+            for (int j = 0; j < P; ++j) S[blk][i][j] = 0.0;
+        }
+
+    // time index 0: (ode_init, 0) for filt and pred (solve.py:114-121)
+#pragma unroll
+    for (int blk = 0; blk < D; ++blk)
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const size_t em = (size_t)blk * P + i;
+            a.mean[em * B + b] = mu[blk][i];
+            if (STORE_PRED) a.mean_pred[em * B + b] = mu[blk][i];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                a.var[(em * P + j) * B + b] = 0.0;
+                if (STORE_PRED) a.var_pred[(em * P + j) * B + b] = 0.0;
+            }
+        }
+
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+    const size_t mstride = (size_t)D * P * B, vstride = (size_t)D * P * P * B;
+    for (int n = 0; n < a.N; ++n) {
+        double mup[D][P], Sp[D][P][P];
+#pragma unroll
+        for (int blk = 0; blk < D; ++blk) predict_block<P>(Q[blk], R[blk], mu[blk], S[blk], mup[blk], Sp[blk]);
+
+        const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
+        double wgt[D][P], am[D], V[D];
+        interrogate_traj<RHS, P, ITG>(W, th, t, mup, Sp, a.seed, traj, (uint32_t)n, wgt, am, V);
+
+        double* mo = a.mean + (size_t)(n + 1) * mstride + b;
+        double* vo = a.var + (size_t)(n + 1) * vstride + b;
+#pragma unroll
+        for (int blk = 0; blk < D; ++blk) {
+            double Wm[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) Wm[j] = W[blk][j] + wgt[blk][j];                      // solve.py:79
+            update_block_m1<P>(Wm, am[blk], V[blk], mup[blk], Sp[blk], mu[blk], S[blk]);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const size_t em = (size_t)blk * P + i;
+                mo[em * B] = mu[blk][i];
+#pragma unroll
+                for (int j = 0; j < P; ++j) vo[(em * P + j) * B] = S[blk][i][j];
+            }
+        }
+        if (STORE_PRED) {
+            double* mpo = a.mean_pred + (size_t)(n + 1) * mstride + b;
+            double* vpo = a.var_pred + (size_t)(n + 1) * vstride + b;
+#pragma unroll
+            for (int blk = 0; blk < D; ++blk)
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const size_t em = (size_t)blk * P + i;
+                    mpo[em * B] = mup[blk][i];
+#pragma unroll
+                    for (int j = 0; j < P; ++j) vpo[(em * P + j) * B] = Sp[blk][i][j];
+                }
+        }
+    }
+}
+
+// ---- backward passes: one lane per (block, trajectory) -----------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void load_filt(const SolveArgs& a, int n, int blk, int b, double (&mf)[P],
+                                          double (&Sf)[P][P]) {
+    const size_t B = (size_t)a.B;
+    const double* mi = a.mean + ((size_t)n * a.D + blk) * P * B + b;
+    const double* vi = a.var + ((size_t)n * a.D + blk) * P * P * B + b;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        mf[i] = mi[(size_t)i * B];
+#pragma unroll
+        for (int j = 0; j < P; ++j) Sf[i][j] = vi[((size_t)i * P + j) * B];
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(64) bwd_mv_kernel(SolveArgs a) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.B * a.D) return;
+    const int blk = l / a.B, b = l - blk * a.B;
+    const size_t B = (size_t)a.B;
+    double Q[P][P], R[P][P];
+    load_block_consts<P>(a, blk, b, Q, R);
+
+    double ms[P], Ss[P][P];                    // carry: smoothed moments at n+1 (solve.py:279-282)
+    load_filt<P>(a, a.N, blk, b, ms, Ss);
+    double mf[P], Sf[P][P];
+    if (a.N >= 2) load_filt<P>(a, a.N - 1, blk, b, mf, Sf);
+    for (int n = a.N - 1; n >= 1; --n) {
+        // software prefetch of the next (earlier) filtered state while this step computes
+        double mfn[P], Sfn[P][P];
+        if (n >= 2) load_filt<P>(a, n - 1, blk, b, mfn, Sfn);
+        double mp[P], Sp[P][P], T[P][P], G[P][P];
+        predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] re-evaluated from filt[n]
+        smooth_gain<P>(Q, Sf, Sp, T, G);
+        smooth_mv_block<P>(G, mf, Sf, mp, Sp, ms, Ss);
+        double* mo = a.mean + ((size_t)n * a.D + blk) * P * B + b;
+        double* vo = a.var + ((size_t)n * a.D + blk) * P * P * B + b;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            mo[(size_t)i * B] = ms[i];
+#pragma unroll
+            for (int j = 0; j < P; ++j) vo[((size_t)i * P + j) * B] = Ss[i][j];
+        }
+        if (n >= 2) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                mf[i] = mfn[i];
+#pragma unroll
+                for (int j = 0; j < P; ++j) Sf[i][j] = Sfn[i][j];
+            }
+        }
+    }
+    // time 0 keeps (ode_init, 0) written by the forward pass (solve.py:295-301)
+}
+
+template <int P>
+__global__ void __launch_bounds__(64) bwd_sim_kernel(SolveArgs a) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.B * a.D) return;
+    const int blk = l / a.B, b = l - blk * a.B;
+    const size_t B = (size_t)a.B;
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+    double Q[P][P], R[P][P];
+    load_block_consts<P>(a, blk, b, Q, R);
+
+    auto store_x = [&](int n, const double (&x)[P]) {
+        double* xo = a.x + ((size_t)n * a.D + blk) * P * B + b;
+#pragma unroll
+        for (int i = 0; i < P; ++i) xo[(size_t)i * B] = x[i];
+    };
+
+    double mf[P], Sf[P][P], xn[P], z[P];
+    // terminal draw x_N ~ N(filt[N]) (solve.py:182-186)
+    load_filt<P>(a, a.N, blk, b, mf, Sf);
+    normals<P>(a.seed, traj, (uint32_t)a.N, (uint32_t)blk, PURPOSE_SMOOTH, z);
+    mvn_draw<P>(mf, Sf, z, xn);
+    store_x(a.N, xn);
+    if (a.N >= 2) load_filt<P>(a, a.N - 1, blk, b, mf, Sf);
+    for (int n = a.N - 1; n >= 1; --n) {
+        double mfn[P], Sfn[P][P];
+        if (n >= 2) load_filt<P>(a, n - 1, blk, b, mfn, Sfn);
+        double mp[P], Sp[P][P], T[P][P], G[P][P], msim[P], Ssim[P][P];
+        predict_block<P>(Q, R, mf, Sf, mp, Sp);
+        smooth_gain<P>(Q, Sf, Sp, T, G);
+        smooth_sim_block<P>(G, T, mf, Sf, mp, xn, msim, Ssim);
+        normals<P>(a.seed, traj, (uint32_t)n, (uint32_t)blk, PURPOSE_SMOOTH, z);
+        mvn_draw<P>(msim, Ssim, z, xn);
+        store_x(n, xn);
+        if (n >= 2) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                mf[i] = mfn[i];
+#pragma unroll
+                for (int j = 0; j < P; ++j) Sf[i][j] = Sfn[i][j];
+            }
+        }
+    }
+    // x[0] = ode_init exactly (solve.py:196-204)
+    double x0[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) x0[i] = a.mean[((size_t)blk * P + i) * B + b];
+    store_x(0, x0);
+}
+
+// ---- one interrogation for a batch (per-step boundary) ------------------------------------------------------------
+template <class RHS, int P, int ITG>
+__global__ void __launch_bounds__(64) interrogate_kernel(SolveArgs a, double t, int step, const double* mean_pred,
+                                                         const double* var_pred, double* wgt_meas,
+                                                         double* mean_meas, double* var_meas) {
+    constexpr int D = RHS::D;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const size_t B = (size_t)a.B;
+    double W[D][P], th[RHS::NTHETA], mup[D][P], Sp[D][P][P];
+#pragma unroll
+    for (int blk = 0; blk < D; ++blk)
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const size_t em = (size_t)blk * P + i;
+            W[blk][i] = ld(a.W, em, a.W_b, a.B, b);
+            mup[blk][i] = mean_pred[em * B + b];
+#pragma unroll
+            for (int j = 0; j < P; ++j) Sp[blk][i][j] = var_pred[(em * P + j) * B + b];
+        }
+#pragma unroll
+    for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
+    double wgt[D][P], am[D], V[D];
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+    interrogate_traj<RHS, P, ITG>(W, th, t, mup, Sp, a.seed, traj, (uint32_t)step, wgt, am, V);
+#pragma unroll
+    for (int blk = 0; blk < D; ++blk) {
+        mean_meas[(size_t)blk * B + b] = am[blk];
+        var_meas[(size_t)blk * B + b] = V[blk];
+#pragma unroll
+        for (int j = 0; j < P; ++j) wgt_meas[((size_t)blk * P + j) * B + b] = wgt[blk][j];
+    }
+}
+
+// ---- Gaussian observation log-posterior reduction (docs/examples/parameter.md:188-210) ---------------------------
+__global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, const double* x, const double* obs, const int32_t* obs_ind,
+                                     int n_obs, double noise_sd, const double* upars, int n_prior, double prior_sd,
+                                     double* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double LOG_SQRT_2PI = 0.91893853320467274178;
+    const double lsd = log(noise_sd);
+    double acc = 0.0;
+    for (int k = 0; k < n_obs; ++k) {
+        int ni = obs_ind[k];
+        ni = ni < 0 ? 0 : (ni > n_steps ? n_steps : ni);     // never index outside the (N+1)-long path
+        const size_t n = (size_t)ni;
+        for (int blk = 0; blk < D; ++blk) {
+            const double xv = x[((n * D + blk) * P + 0) * (size_t)B + b];
+            const double zz = (obs[(size_t)k * D + blk] - xv) / noise_sd;
+            acc += -0.5 * zz * zz - lsd - LOG_SQRT_2PI;       // scipy.stats.norm.logpdf
+        }
+    }
+    if (upars) {
+        const double lps = log(prior_sd);
+        for (int k = 0; k < n_prior; ++k) {
+            const double zz = upars[(size_t)k * B + b] / prior_sd;
+            acc += -0.5 * zz * zz - lps - LOG_SQRT_2PI;
+        }
+    }
+    out[b] = acc;
+}
+
+// ---- dispatch ---------------------------------------------------------------------------------------------------
+static int make_args(const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, SolveArgs& a) {
+    a.B = c->n_traj; a.N = c->n_steps; a.D = c->n_block;
+    a.t_min = c->t_min; a.t_max = c->t_max; a.seed = c->seed; a.traj_offset = c->traj_offset;
+    a.W = in->ode_weight; a.W_b = in->ode_weight_batched;
+    a.x0 = in->ode_init; a.x0_b = in->ode_init_batched;
+    a.Q = in->prior_weight; a.Q_b = in->prior_weight_batched;
+    a.R = in->prior_var; a.R_b = in->prior_var_batched;
+    a.theta = in->theta; a.theta_b = in->theta_batched;
+    a.mean = out ? out->mean_state : nullptr; a.var = out ? out->var_state : nullptr;
+    a.mean_pred = out ? out->mean_pred : nullptr; a.var_pred = out ? out->var_pred : nullptr;
+    a.x = out ? out->x_state : nullptr;
+    return RK_OK;
+}
+
+static int check_cfg(const rk_solve_cfg* c, const rk_solve_in* in) {
+    RK_REQUIRE(c && in, RK_ERR_INVALID, "null cfg / in");
+    RK_REQUIRE(c->n_traj >= 1 && c->n_steps >= 1 && c->n_block >= 1 && c->n_bstate >= 1 && c->n_bmeas >= 1,
+               RK_ERR_INVALID, "non-positive dimension (n_traj=%d n_steps=%d n_block=%d n_bstate=%d n_bmeas=%d)",
+               c->n_traj, c->n_steps, c->n_block, c->n_bstate, c->n_bmeas);
+    RK_REQUIRE(in->ode_weight && in->ode_init && in->prior_weight && in->prior_var, RK_ERR_INVALID,
+               "ode_weight / ode_init / prior_weight / prior_var must not be NULL");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD || c->kalman_type == RK_KALMAN_SQRT, RK_ERR_UNSUPPORTED,
+               "unknown kalman_type %d", c->kalman_type);
+    RK_REQUIRE(c->interrogate >= 0 && c->interrogate <= 3, RK_ERR_UNSUPPORTED, "unknown interrogate id %d",
+               c->interrogate);
+    return RK_OK;
+}
+
+template <class RHS, int P, int ITG>
+static int launch_fwd_t(rk_handle h, const SolveArgs& a, bool store_pred) {
+    const dim3 grid(div_up(a.B, 64)), block(64);
+    LaunchTimer t(h, "fwd_kernel");
+    if (store_pred) hipLaunchKernelGGL((fwd_kernel<RHS, P, ITG, true>), grid, block, 0, h->stream, a);
+    else hipLaunchKernelGGL((fwd_kernel<RHS, P, ITG, false>), grid, block, 0, h->stream, a);
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+template <class RHS, int P>
+static int launch_fwd_p(rk_handle h, const SolveArgs& a, int itg, bool sp) {
+    switch (itg) {
+        case RK_INTERROGATE_RODEO: return launch_fwd_t<RHS, P, RK_INTERROGATE_RODEO>(h, a, sp);
+        case RK_INTERROGATE_SCHOBER: return launch_fwd_t<RHS, P, RK_INTERROGATE_SCHOBER>(h, a, sp);
+        case RK_INTERROGATE_KRAMER: return launch_fwd_t<RHS, P, RK_INTERROGATE_KRAMER>(h, a, sp);
+        case RK_INTERROGATE_CHKREBTII: return launch_fwd_t<RHS, P, RK_INTERROGATE_CHKREBTII>(h, a, sp);
+    }
+    set_error("unknown interrogate id %d", itg);
+    return RK_ERR_UNSUPPORTED;
+}
+
+template <class RHS>
+static int launch_fwd_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
+    RK_REQUIRE(c->n_block == RHS::D && c->n_bmeas == 1, RK_ERR_UNSUPPORTED,
+               "rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, RHS::D, c->n_block, c->n_bmeas);
+    RK_REQUIRE(c->n_theta == 0 || c->n_theta >= RHS::NTHETA || !a.theta, RK_ERR_INVALID,
+               "rhs %d needs %d parameters, got n_theta=%d", c->rhs_id, RHS::NTHETA, c->n_theta);
+    const bool sp = (c->flags & RK_FLAG_STORE_PRED) != 0;
+    switch (c->n_bstate) {
+        case 2: return launch_fwd_p<RHS, 2>(h, a, c->interrogate, sp);
+        case 3: return launch_fwd_p<RHS, 3>(h, a, c->interrogate, sp);
+        case 4: return launch_fwd_p<RHS, 4>(h, a, c->interrogate, sp);
+        case 5: return launch_fwd_p<RHS, 5>(h, a, c->interrogate, sp);
+    }
+    set_error("small-block path supports n_bstate in [2, 5], got %d", c->n_bstate);
+    return RK_ERR_UNSUPPORTED;
+}
+
+int small_forward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
+    switch (c->rhs_id) {
+        case RK_RHS_FITZHUGH_NAGUMO: return launch_fwd_rhs<FitzHughNagumo>(h, c, a);
+        case RK_RHS_LORENZ63: return launch_fwd_rhs<Lorenz63>(h, c, a);
+        case RK_RHS_HIGHER_ORDER: return launch_fwd_rhs<HigherOrder>(h, c, a);
+    }
+    set_error("unknown rhs_id %d for the small-block path", c->rhs_id);
+    return RK_ERR_UNSUPPORTED;
+}
+
+template <bool SIM>
+static int small_backward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
+    const dim3 grid(div_up(a.B * a.D, 64)), block(64);
+    LaunchTimer t(h, SIM ? "bwd_sim_kernel" : "bwd_mv_kernel");
+#define RK_BWD(P_)                                                                              \
+    case P_:                                                                                    \
+        if (SIM) hipLaunchKernelGGL((bwd_sim_kernel<P_>), grid, block, 0, h->stream, a);        \
+        else hipLaunchKernelGGL((bwd_mv_kernel<P_>), grid, block, 0, h->stream, a);             \
+        break;
+    switch (c->n_bstate) {
+        RK_BWD(2) RK_BWD(3) RK_BWD(4) RK_BWD(5)
+        default:
+            set_error("small-block path supports n_bstate in [2, 5], got %d", c->n_bstate);
+            return RK_ERR_UNSUPPORTED;
+    }
+#undef RK_BWD
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+template <class RHS>
+static int launch_itg_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double t, int step,
+                          const double* mp, const double* vp, double* wm, double* mm_, double* vm) {
+    RK_REQUIRE(c->n_block == RHS::D && c->n_bmeas == 1, RK_ERR_UNSUPPORTED,
+               "rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, RHS::D, c->n_block, c->n_bmeas);
+    const dim3 grid(div_up(a.B, 64)), block(64);
+#define RK_ITG2(P_, I_)                                                                                          \
+    hipLaunchKernelGGL((interrogate_kernel<RHS, P_, I_>), grid, block, 0, h->stream, a, t, step, mp, vp, wm, mm_, vm)
+#define RK_ITG(P_)                                                                      \
+    case P_:                                                                            \
+        switch (c->interrogate) {                                                       \
+            case RK_INTERROGATE_RODEO: RK_ITG2(P_, RK_INTERROGATE_RODEO); break;        \
+            case RK_INTERROGATE_SCHOBER: RK_ITG2(P_, RK_INTERROGATE_SCHOBER); break;    \
+            case RK_INTERROGATE_KRAMER: RK_ITG2(P_, RK_INTERROGATE_KRAMER); break;      \
+            case RK_INTERROGATE_CHKREBTII: RK_ITG2(P_, RK_INTERROGATE_CHKREBTII); break; \
+        }                                                                               \
+        break;
+    switch (c->n_bstate) {
+        RK_ITG(2) RK_ITG(3) RK_ITG(4) RK_ITG(5)
+        default:
+            set_error("small-block path supports n_bstate in [2, 5], got %d", c->n_bstate);
+            return RK_ERR_UNSUPPORTED;
+    }
+#undef RK_ITG
+#undef RK_ITG2
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+}  // namespace rk
+
+using namespace rk;
+
+extern "C" {
+
+int rk_solve_sizes(const rk_solve_cfg* c, size_t* mean_bytes, size_t* var_bytes) {
+    RK_REQUIRE(c, RK_ERR_INVALID, "rk_solve_sizes: null cfg");
+    const size_t m = (size_t)(c->n_steps + 1) * c->n_block * c->n_bstate * (size_t)c->n_traj * sizeof(double);
+    if (mean_bytes) *mean_bytes = m;
+    if (var_bytes) *var_bytes = m * c->n_bstate;
+    return RK_OK;
+}
+
+static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out,
+                        int mode /*0 filter, 1 mv, 2 sim*/) {
+    RK_REQUIRE(h, RK_ERR_INVALID, "null handle");
+    int rc = check_cfg(c, in);
+    if (rc) return rc;
+    RK_REQUIRE(out && out->mean_state && out->var_state, RK_ERR_INVALID, "out->mean_state / var_state must not be NULL");
+    RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED) || (out->mean_pred && out->var_pred), RK_ERR_INVALID,
+               "RK_FLAG_STORE_PRED needs out->mean_pred / var_pred");
+    RK_REQUIRE(mode != 2 || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED,
+               "kalman_type=square-root is not available in the fused solver yet");
+    RK_HIP(hipSetDevice(h->device));
+    h->prof.clear();
+    h->event_used = 0;
+    SolveArgs a;
+    make_args(c, in, out, a);
+    rc = small_forward(h, c, a);
+    if (rc) return rc;
+    if (mode == 1) rc = small_backward<false>(h, c, a);
+    if (mode == 2) rc = small_backward<true>(h, c, a);
+    return rc;
+}
+
+int rk_solve_filter(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out) {
+    return solve_common(h, c, in, out, 0);
+}
+int rk_solve_mv(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out) {
+    return solve_common(h, c, in, out, 1);
+}
+int rk_solve_sim(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out) {
+    return solve_common(h, c, in, out, 2);
+}
+
+int rk_interrogate_batched(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, double t, int32_t step,
+                           const double* mean_state_pred, const double* var_state_pred, double* wgt_meas,
+                           double* mean_meas, double* var_meas) {
+    RK_REQUIRE(h, RK_ERR_INVALID, "null handle");
+    RK_REQUIRE(c && in && in->ode_weight, RK_ERR_INVALID, "rk_interrogate_batched: null cfg / in / ode_weight");
+    RK_REQUIRE(mean_state_pred && var_state_pred && wgt_meas && mean_meas && var_meas, RK_ERR_INVALID,
+               "rk_interrogate_batched: null array");
+    RK_REQUIRE(c->n_traj >= 1, RK_ERR_INVALID, "rk_interrogate_batched: n_traj must be positive");
+    RK_HIP(hipSetDevice(h->device));
+    SolveArgs a;
+    make_args(c, in, nullptr, a);
+    switch (c->rhs_id) {
+        case RK_RHS_FITZHUGH_NAGUMO:
+            return launch_itg_rhs<FitzHughNagumo>(h, c, a, t, step, mean_state_pred, var_state_pred, wgt_meas, mean_meas, var_meas);
+        case RK_RHS_LORENZ63:
+            return launch_itg_rhs<Lorenz63>(h, c, a, t, step, mean_state_pred, var_state_pred, wgt_meas, mean_meas, var_meas);
+        case RK_RHS_HIGHER_ORDER:
+            return launch_itg_rhs<HigherOrder>(h, c, a, t, step, mean_state_pred, var_state_pred, wgt_meas, mean_meas, var_meas);
+    }
+    set_error("unknown rhs_id %d", c->rhs_id);
+    return RK_ERR_UNSUPPORTED;
+}
+
+int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n_block, int32_t n_bstate,
+                         const double* x_state, const double* obs, const int32_t* obs_ind, int32_t n_obs,
+                         double noise_sd, const double* upars, int32_t n_prior, double prior_sd, double* logpost) {
+    RK_REQUIRE(h && x_state && obs && obs_ind && logpost, RK_ERR_INVALID, "rk_gauss_obs_logpost: null argument");
+    RK_REQUIRE(n_traj >= 1 && n_obs >= 0 && n_block >= 1 && n_bstate >= 1 && n_steps >= 1, RK_ERR_INVALID,
+               "rk_gauss_obs_logpost: bad dimension");
+    RK_HIP(hipSetDevice(h->device));
+    LaunchTimer t(h, "gauss_logpost_kernel");
+    hipLaunchKernelGGL(gauss_logpost_kernel, dim3(div_up(n_traj, 64)), dim3(64), 0, h->stream, n_traj, n_steps, n_block,
+                       n_bstate, x_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+"""
+Device plumbing above the C ABI: one ``Device`` = one rk_handle (one HIP device + one stream), and ``DeviceArray``
+= a device buffer tagged with its logical per-trajectory shape in the batch-minor layout of
+include/rodeo_kalman.h (element e of trajectory b at ``ptr[e * B + b]``).
+"""
+import ctypes as C
+import os
+import numpy as np
+from . import _lib
+
+
+class Device:
+    def __init__(self, device_id=None):
+        lib = _lib.load()
+        if device_id is None:
+            device_id = int(os.environ.get("LOCAL_RANK", "0"))
+            n = C.c_int(0)
+            _lib.check(lib.rk_device_count(C.byref(n)))
+            device_id = device_id % max(n.value, 1)
+        self.lib = lib
+        self.device_id = device_id
+        h = C.c_void_p()
+        _lib.check(lib.rk_create(device_id, C.byref(h)))
+        self.h = h
+        self.rank, self.nranks = 0, 1
+
+    # ---- memory ----
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        _lib.check(self.lib.rk_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def free(self, ptr):
+        if self.h:
+            _lib.check(self.lib.rk_free(self.h, ptr))
+
+    def sync(self):
+        _lib.check(self.lib.rk_sync(self.h))
+
+    def name(self):
+        buf = C.create_string_buffer(256)
+        _lib.check(self.lib.rk_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    # ---- arrays ----
+    def empty(self, shape, dtype=np.float64):
+        return DeviceArray(self, tuple(int(s) for s in shape), np.dtype(dtype))
+
+    def zeros(self, shape, dtype=np.float64):
+        a = self.empty(shape, dtype)
+        _lib.check(self.lib.rk_memset(self.h, a.ptr, 0, a.nbytes))
+        return a
+
+    def to_device(self, host):
+        host = np.ascontiguousarray(host)
+        a = self.empty(host.shape, host.dtype)
+        if a.nbytes:
+            _lib.check(self.lib.rk_h2d(self.h, a.ptr, host.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+
+    # ---- timing on the handle's stream ----
+    def timer_start(self):
+        _lib.check(self.lib.rk_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_double(0.0)
+        _lib.check(self.lib.rk_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        _lib.check(self.lib.rk_profile_enable(self.h, 1 if on else 0))
+
+    def profile_last(self, cap=16):
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        n = C.c_int(0)
+        _lib.check(self.lib.rk_profile_last(self.h, cap, names, ms, C.byref(n)))
+        return [(names[i].decode(), ms[i]) for i in range(min(n.value, cap))]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceArray:
+    """A device buffer of a given shape/dtype (C-contiguous).  Freed when garbage-collected."""
+
+    def __init__(self, dev, shape, dtype):
+        self.dev, self.shape, self.dtype = dev, shape, dtype
+        self.nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        self.ptr = dev.alloc(self.nbytes) if self.nbytes else C.c_void_p()
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            _lib.check(self.dev.lib.rk_d2h(self.dev.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def batch_first(self):
+        """Download a batch-minor array (S..., B) and return the (B, S...) strided view (no extra copy)."""
+        return np.moveaxis(self.to_host(), -1, 0)
+
+    def __del__(self):
+        try:
+            if self.nbytes and self.dev.h:
+                self.dev.free(self.ptr)
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def default_device():
+    """Process-wide default handle (device LOCAL_RANK % n_devices)."""
+    global _default
+    if _default is None:
+        _default = Device()
+    return _default
+
+
+def batch_minor(host, batched):
+    """(B, S...) -> contiguous (S..., B) for batched inputs; shared inputs stay (S...)."""
+    host = np.asarray(host, dtype=np.float64)
+    if batched:
+        return np.ascontiguousarray(np.moveaxis(host, 0, -1))
+    return np.ascontiguousarray(host)

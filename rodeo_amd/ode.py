@@ -1,0 +1,82 @@
+"""
+ODE right-hand sides usable on the device.
+
+In rodeo the ODE is an arbitrary JAX-traceable Python callable ``ode_fun(X, t, **params)`` evaluated inside the
+scan (src/rodeo/solve.py:70-78) and differentiated with ``jax.jacfwd`` for ``interrogate_kramer``
+(src/rodeo/interrogate.py:76).  Here the whole time loop runs inside one GPU kernel, so the right-hand side must
+exist as device code: a ``DeviceODE`` couples
+
+  * ``rhs_id``      -- the device implementation (rodeo_amd/csrc/rhs.hpp) compiled into the fused kernels,
+  * ``__call__``    -- the same function in NumPy with rodeo's calling convention, used host-side for input
+                       preparation only (``first_order_pad(...)[1]``, src/rodeo/utils.py:96-98),
+  * ``param_spec``  -- how ``**params`` are packed into the per-trajectory parameter vector ``theta``.
+
+Passing a plain Python callable to ``solve_mv`` / ``solve_sim`` raises ``TypeError`` -- there is no CPU fallback.
+"""
+import numpy as np
+from . import _lib
+
+
+class DeviceODE:
+    def __init__(self, name, rhs_id, n_block, n_bmeas, param_spec, host_fun):
+        self.name, self.rhs_id, self.n_block, self.n_bmeas = name, rhs_id, n_block, n_bmeas
+        self.param_spec = tuple(param_spec)          # ((kwarg name, size), ...)
+        self._host_fun = host_fun
+
+    def __call__(self, X, t, **params):
+        return self._host_fun(np.asarray(X, dtype=np.float64), t, **params)
+
+    @property
+    def n_theta(self):
+        return sum(s for _, s in self.param_spec)
+
+    def pack_params(self, params):
+        """-> (theta, batch): theta (n_theta,) if no parameter is batched else (B, n_theta); batch = B or None."""
+        parts, B = [], None
+        for name, size in self.param_spec:
+            if name not in params:
+                raise TypeError(f"ODE '{self.name}' needs the parameter '{name}' (size {size})")
+            v = np.asarray(params[name], dtype=np.float64)
+            if v.ndim == 0 and size == 1:
+                v = v[None]
+            if v.ndim == 0 or v.shape[-1] != size or v.ndim > 2:
+                raise ValueError(f"parameter '{name}' must have shape ({size},) or (B, {size}), got {v.shape}")
+            if v.ndim == 2:
+                if B not in (None, v.shape[0]):
+                    raise ValueError("inconsistent batch sizes among ODE parameters")
+                B = v.shape[0]
+            parts.append(v)
+        extra = set(params) - {n for n, _ in self.param_spec}
+        if extra:
+            raise TypeError(f"ODE '{self.name}' got unexpected parameters {sorted(extra)}")
+        if not parts:
+            return np.zeros(0), None
+        if B is not None:
+            parts = [np.broadcast_to(v, (B, v.shape[-1])) for v in parts]
+        return np.concatenate(parts, axis=-1), B
+
+
+def _fitz(X, t, theta):
+    theta = np.asarray(theta, dtype=np.float64)
+    a, b, c = theta[..., 0], theta[..., 1], theta[..., 2]
+    V, R = X[..., 0, 0], X[..., 1, 0]
+    return np.stack([c * (V - V * V * V / 3 + R), -1 / c * (V - a + b * R)], axis=-1)[..., None]
+
+
+def _lorenz(X, t, theta):
+    theta = np.asarray(theta, dtype=np.float64)
+    rho, sigma, beta = theta[..., 0], theta[..., 1], theta[..., 2]
+    x, y, z = X[..., 0, 0], X[..., 1, 0], X[..., 2, 0]
+    return np.stack([-sigma * x + sigma * y, rho * x - y - x * z, -beta * z + x * y], axis=-1)[..., None]
+
+
+def _higher(X, t):
+    return (np.sin(2 * t) - X[..., 0, 0])[..., None, None]
+
+
+#: FitzHugh-Nagumo (README.md:92-99); ``theta = (a, b, c)``
+fitzhugh_nagumo = DeviceODE("fitzhugh_nagumo", _lib.RHS_FITZHUGH_NAGUMO, 2, 1, (("theta", 3),), _fitz)
+#: Lorenz63 (docs/examples/lorenz.md:85-92); ``theta = (rho, sigma, beta)``
+lorenz63 = DeviceODE("lorenz63", _lib.RHS_LORENZ63, 3, 1, (("theta", 3),), _lorenz)
+#: x'' = sin(2t) - x (docs/examples/higher_order.md:47-59); no parameters
+higher_order = DeviceODE("higher_order", _lib.RHS_HIGHER_ORDER, 1, 1, (), _higher)

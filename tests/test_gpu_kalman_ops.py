@@ -1,0 +1,159 @@
+"""
+GPU parity of the per-step operator boundary (rk_kalman_*_batched through rodeo_amd.kalmantv.*):
+  * against the reference's own test oracle K1 (joint-Gaussian conditioning), exactly as tests/test_standard.py /
+    tests/test_square_root.py of the reference do, tolerance 5e-8 in the reference's rel_err metric;
+  * against oracle/kalman_ops.py / sqrt_ops.py on random batches (single-step maps on identical inputs): tight.
+"""
+import numpy as np
+import pytest
+from oracle import kalman_ops as oktv, sqrt_ops as osq, joint_gaussian as jg
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-8
+
+
+@pytest.fixture(scope="module")
+def ktv():
+    import rodeo_amd.kalmantv.standard as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def sq():
+    import rodeo_amd.kalmantv.square_root as m
+    return m
+
+
+@pytest.fixture(params=range(6))
+def mdl(request):
+    return jg.random_model(np.random.default_rng(3000 + request.param))
+
+
+def _close(a, b, tol=TOL):
+    assert np.shape(a) == np.shape(b)
+    assert jg.rel_err(a, b) < tol
+
+
+def test_standard_vs_joint_gaussian(ktv, mdl):
+    for step in (1, 2):
+        past, pred, filt = jg.filter_targets(mdl, step)
+        kw = dict(mean_state=mdl["mean_state"][step], wgt_state=mdl["wgt_state"][step - 1],
+                  var_state=mdl["var_state"][step])
+        kwm = dict(x_meas=mdl["x_meas"][step], mean_meas=mdl["mean_meas"][step], wgt_meas=mdl["wgt_meas"][step],
+                   var_meas=mdl["var_meas"][step])
+        mp, vp = ktv.predict(mean_state_past=past[0], var_state_past=past[1], **kw)
+        _close(pred[0], mp); _close(pred[1], vp)
+        mf, vf = ktv.update(mean_state_pred=pred[0], var_state_pred=pred[1], **kwm)
+        _close(filt[0], mf); _close(filt[1], vf)
+        out = ktv.filter(mean_state_past=past[0], var_state_past=past[1], **kw, **kwm)
+        for a, b in zip((pred[0], pred[1], filt[0], filt[1]), out):
+            _close(a, b)
+    t = jg.smooth_targets(mdl)
+    sm = dict(mean_state_filt=t["filt"][0], var_state_filt=t["filt"][1], mean_state_pred=t["pred"][0],
+              var_state_pred=t["pred"][1], wgt_state=mdl["wgt_state"][0])
+    m2, v2 = ktv.smooth_mv(mean_state_next=t["next"][0], var_state_next=t["next"][1], **sm)
+    _close(t["smooth"][0], m2); _close(t["smooth"][1], v2)
+    m3, v3 = ktv.smooth_sim(x_state_next=mdl["x_state_next"], **sm)
+    _close(t["sim"][0], m3); _close(t["sim"][1], v3)
+    o = ktv.smooth(x_state_next=mdl["x_state_next"], mean_state_next=t["next"][0], var_state_next=t["next"][1], **sm)
+    _close(t["sim"][0], o[0]); _close(t["sim"][1], o[1]); _close(t["smooth"][0], o[2]); _close(t["smooth"][1], o[3])
+    A2, b2, V2 = ktv.smooth_cond(**sm)
+    A, b, V = t["cond"]
+    _close(A, A2); _close(b, b2); _close(V, V2)
+
+
+def _rand_batch(rng, n, p, m):
+    def spd(k, lead):
+        a = rng.standard_normal(lead + (k, k))
+        return a @ np.swapaxes(a, -1, -2) + 0.1 * np.eye(k)
+    return dict(mu=rng.standard_normal((n, p)), S=spd(p, (n,)), Q=0.3 * rng.standard_normal((n, p, p)),
+                R=spd(p, (n,)), c=rng.standard_normal((n, p)), W=rng.standard_normal((n, m, p)), V=spd(m, (n,)),
+                a=rng.standard_normal((n, m)), x=rng.standard_normal((n, m)), xn=rng.standard_normal((n, p)),
+                mn=rng.standard_normal((n, p)), Sn=spd(p, (n,)))
+
+
+@pytest.mark.parametrize("p,m", [(2, 1), (3, 1), (4, 2), (6, 3), (8, 1), (12, 4), (16, 2)])
+def test_standard_vs_oracle_batches(ktv, p, m):
+    r = _rand_batch(np.random.default_rng(p * 10 + m), 130, p, m)           # 130: not a multiple of the wave size
+    mp, vp = ktv.predict(r["mu"], r["S"], r["c"], r["Q"], r["R"])
+    omp, ovp = oktv.predict(r["mu"], r["S"], r["c"], r["Q"], r["R"])
+    np.testing.assert_allclose(mp, omp, rtol=1e-12, atol=1e-12); np.testing.assert_allclose(vp, ovp, rtol=1e-12, atol=1e-12)
+    mf, vf = ktv.update(omp, ovp, r["x"], r["a"], r["W"], r["V"])
+    omf, ovf = oktv.update(omp, ovp, r["x"], r["a"], r["W"], r["V"])
+    np.testing.assert_allclose(mf, omf, rtol=1e-9, atol=1e-10); np.testing.assert_allclose(vf, ovf, rtol=1e-9, atol=1e-10)
+    fo = ktv.forecast(omp, ovp, r["a"], r["W"], r["V"])
+    ofo = oktv.forecast(omp, ovp, r["a"], r["W"], r["V"])
+    np.testing.assert_allclose(fo[0], ofo[0], rtol=1e-12, atol=1e-12); np.testing.assert_allclose(fo[1], ofo[1], rtol=1e-12, atol=1e-12)
+    sm = ktv.smooth(r["xn"], r["mn"], r["Sn"], omf, ovf, omp, ovp, r["Q"])
+    osm = oktv.smooth(r["xn"], r["mn"], r["Sn"], omf, ovf, omp, ovp, r["Q"])
+    for g, o in zip(sm, osm):
+        np.testing.assert_allclose(g, o, rtol=1e-8, atol=1e-9)
+    sc = ktv.smooth_cond(omf, ovf, omp, ovp, r["Q"])
+    osc = oktv.smooth_cond(omf, ovf, omp, ovp, r["Q"])
+    for g, o in zip(sc, osc):
+        np.testing.assert_allclose(g, o, rtol=1e-8, atol=1e-9)
+
+
+def test_broadcast_and_kwargs(ktv):
+    """Leading dims broadcast like vmap; unknown kwargs are swallowed (standard.py:36)."""
+    rng = np.random.default_rng(0)
+    p = 3
+    mu = rng.standard_normal((2, 5, p)); a = rng.standard_normal((5, p, p)); S = a @ np.swapaxes(a, -1, -2)
+    Q = rng.standard_normal((p, p)); R = np.eye(p)
+    mp, vp = ktv.predict(mean_state_past=mu, var_state_past=S, mean_state=np.zeros(p), wgt_state=Q, var_state=R,
+                         extra_kwarg=1)
+    assert mp.shape == (2, 5, p) and vp.shape == (2, 5, p, p)
+    o = oktv.predict(mu, S, np.zeros(p), Q, R)
+    np.testing.assert_allclose(mp, o[0], rtol=1e-12, atol=1e-13); np.testing.assert_allclose(vp, np.broadcast_to(o[1], vp.shape), rtol=1e-12, atol=1e-13)
+    # unbatched call returns unbatched shapes
+    m1, v1 = ktv.predict(mu[0, 0], S[0], np.zeros(p), Q, R)
+    assert m1.shape == (p,) and v1.shape == (p, p)
+
+
+def test_errors(ktv, sq):
+    from rodeo_amd._lib import RodeoKalmanError
+    with pytest.raises(RodeoKalmanError):
+        ktv.predict(np.zeros(20), np.eye(20), np.zeros(20), np.eye(20), np.eye(20))      # n_state > 16 unsupported here
+    with pytest.raises(TypeError):
+        sq.smooth_mv(np.zeros(2), np.eye(2), np.zeros(2), np.eye(2), np.zeros(2), np.eye(2), np.eye(2))  # var_state required
+
+
+def _chol(A):
+    return np.linalg.cholesky(A)
+
+
+def _sqr(L):
+    return L @ np.swapaxes(L, -1, -2)
+
+
+def test_square_root_vs_joint_gaussian(sq, mdl):
+    past, pred, filt = jg.filter_targets(mdl, 1)
+    m2, v2 = sq.predict(past[0], _chol(past[1]), mdl["mean_state"][1], mdl["wgt_state"][0], _chol(mdl["var_state"][1]))
+    _close(pred[0], m2); _close(pred[1], _sqr(v2))
+    m3, v3 = sq.update(pred[0], _chol(pred[1]), mdl["x_meas"][1], mdl["mean_meas"][1], mdl["wgt_meas"][1],
+                       _chol(mdl["var_meas"][1]))
+    _close(filt[0], m3); _close(filt[1], _sqr(v3))
+    t = jg.smooth_targets(mdl)
+    args = dict(mean_state_filt=t["filt"][0], var_state_filt=_chol(t["filt"][1]), mean_state_pred=t["pred"][0],
+                var_state_pred=_chol(t["pred"][1]), wgt_state=mdl["wgt_state"][0], var_state=_chol(mdl["var_state"][1]))
+    mm, vm = sq.smooth_mv(mean_state_next=t["next"][0], var_state_next=_chol(t["next"][1]), **args)
+    _close(t["smooth"][0], mm); _close(t["smooth"][1], _sqr(vm))
+    ms, vs = sq.smooth_sim(x_state_next=mdl["x_state_next"], **args)
+    _close(t["sim"][0], ms); _close(t["sim"][1], _sqr(vs))
+    A2, b2, V2 = sq.smooth_cond(**args)
+    A, b, V = t["cond"]
+    _close(A, A2); _close(b, b2); _close(V, _sqr(V2))
+    f = sq.forecast(pred[0], _chol(pred[1]), mdl["mean_meas"][1], mdl["wgt_meas"][1], _chol(mdl["var_meas"][1]))
+    of = oktv.forecast(pred[0], pred[1], mdl["mean_meas"][1], mdl["wgt_meas"][1], mdl["var_meas"][1])
+    _close(of[0], f[0]); _close(of[1], f[1])
+
+
+def test_square_root_vs_oracle_batch(sq):
+    r = _rand_batch(np.random.default_rng(77), 70, 4, 2)
+    Ls, LR, LV = _chol(r["S"]), _chol(r["R"]), _chol(r["V"])
+    mp, vp = sq.predict(r["mu"], Ls, r["c"], r["Q"], LR)
+    omp, ovp = osq.predict(r["mu"], Ls, r["c"], r["Q"], LR)
+    np.testing.assert_allclose(mp, omp, rtol=1e-12, atol=1e-12); np.testing.assert_allclose(_sqr(vp), _sqr(ovp), rtol=1e-10, atol=1e-11)
+    mf, vf = sq.update(omp, ovp, r["x"], r["a"], r["W"], LV)
+    omf, ovf = osq.update(omp, ovp, r["x"], r["a"], r["W"], LV)
+    np.testing.assert_allclose(mf, omf, rtol=1e-9, atol=1e-10); np.testing.assert_allclose(_sqr(vf), _sqr(ovf), rtol=1e-8, atol=1e-10)

@@ -1,0 +1,258 @@
+"""
+GPU parity of the whole-solve boundary (rk_solve_filter / rk_solve_mv / rk_solve_sim through rodeo_amd.solve) against
+the NumPy oracle on identical seeded inputs, plus the reference's own solver-level oracles evaluated directly on the
+HIP path (K3 odeint, K4 analytic), plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (fp64).  Single-step maps agree to ~1e-13 relative; over a trajectory the IBM covariances are
+ill-conditioned (cond(Sigma_pred) ~ 5e9 for FN at dt = 0.01, SURVEY.md hard part 3) so LU-solve rounding differences
+are amplified; the stated per-trajectory bounds are:
+    FitzHugh-Nagumo / higher-order:  |mean - oracle| <= 1e-9 absolute,  var: 1e-9 relative to max|var|
+    Lorenz63 (chaotic, t <= 2):      |mean - oracle| <= 1e-6 absolute
+and everything is far inside the reference's own 5e-8 rel_err criterion on the non-chaotic problems.
+"""
+import functools
+import numpy as np
+import pytest
+from scipy.integrate import odeint
+from oracle import scan, odes, priors, joint_gaussian as jg, interrogations as oi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rodeo_amd
+    return rodeo_amd
+
+
+def _itg(ra, name):
+    return getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+
+
+def fitz_problem(ra, N=200, t_max=10.0, sigma=.001, p=3, B=None, seed=0):
+    theta = np.array([0.2, 0.2, 3.0])
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0v = np.array([-1., 1.])
+    if B is not None:
+        rng = np.random.default_rng(seed)
+        theta = theta * np.exp(0.1 * rng.standard_normal((B, 3)))
+        x0v = x0v + 0.1 * rng.standard_normal((B, 2))
+    x0 = init(x0v, 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / N, p, np.array([sigma] * 2))
+    return dict(W=W, x0=x0, theta=theta, prior=prior, t_max=t_max, N=N)
+
+
+def _vclose(v, vo, rtol):
+    assert np.max(np.abs(v - vo)) <= rtol * np.max(np.abs(vo))
+
+
+@pytest.mark.parametrize("name", ["rodeo", "schober", "kramer"])
+def test_fitz_mv_and_filter_parity(ra, name):
+    g, o = _itg(ra, name)
+    s = fitz_problem(ra)
+    args = (s["W"], s["x0"], 0.0, s["t_max"], s["N"])
+    m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    assert m.shape == (201, 2, 3) and v.shape == (201, 2, 3, 3)
+    assert np.max(np.abs(m - mo)) < 1e-9
+    _vclose(v, vo, 1e-9)
+    assert jg.rel_err(mo, m) < 5e-8 and jg.rel_err(vo, v) < 5e-8          # the reference's own criterion
+    np.testing.assert_array_equal(m[0], s["x0"]); assert np.all(v[0] == 0)
+    from rodeo_amd.solve import _solve_filter
+    f = _solve_filter(None, ra.ode.fitzhugh_nagumo, *args, g, *s["prior"], theta=s["theta"])
+    fo = scan.solve_filter(None, odes.fitzhugh_nagumo, *args, o, *s["prior"], theta=s["theta"])
+    for k in ("state_pred", "state_filt"):
+        assert np.max(np.abs(f[k][0] - fo[k][0])) < 1e-9
+        _vclose(f[k][1], fo[k][1], 1e-9)
+    np.testing.assert_array_equal(m[-1], f["state_filt"][0][-1])          # solve.py:295-301
+
+
+def test_positional_and_keyword_calls(ra):
+    """solve_mv is called positionally (docs/examples/lorenz.md:143-146) and by keyword (README.md:139-152)."""
+    s = fitz_problem(ra, N=50, t_max=2.5)
+    a = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, 2.5, 50, ra.interrogate.interrogate_kramer,
+                    s["prior"], theta=s["theta"])
+    b = ra.solve_mv(key=None, ode_fun=ra.ode.fitzhugh_nagumo, ode_weight=s["W"], ode_init=s["x0"], t_min=0.0, t_max=2.5,
+                    n_steps=50, interrogate=ra.interrogate.interrogate_kramer, prior_pars=s["prior"],
+                    kalman_type="standard", theta=s["theta"])
+    np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_errors(ra):
+    s = fitz_problem(ra, N=10, t_max=1.0)
+    args = (s["W"], s["x0"], 0.0, 1.0, 10)
+    with pytest.raises(NotImplementedError):                                  # solve.py:142-143
+        ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"],
+                    kalman_type="nope", theta=s["theta"])
+    with pytest.raises(TypeError):
+        ra.solve_mv(None, lambda X, t, **p: X, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
+    with pytest.raises(TypeError):
+        ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, lambda **k: None, s["prior"], theta=s["theta"])
+    with pytest.raises(TypeError):
+        ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"])   # no theta
+    with pytest.raises(ValueError):
+        ra.solve_mv(None, ra.ode.lorenz63, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
+
+
+@pytest.mark.parametrize("B", [1, 7, 64, 100])
+def test_batched_ragged_sizes(ra, B):
+    """Batch sizes that are not multiples of the 64-lane wavefront, batched theta + x0, shared prior."""
+    s = fitz_problem(ra, N=60, t_max=3.0, sigma=.1, B=B, seed=B)
+    args = (s["W"], s["x0"], 0.0, 3.0, 60)
+    m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, s["prior"], theta=s["theta"])
+    assert m.shape == (B, 61, 2, 3)
+    assert np.max(np.abs(m - mo)) < 1e-9
+    _vclose(v, vo, 1e-9)
+
+
+def test_batched_prior_sigma(ra):
+    """Per-trajectory sigma -> batched prior_var (what docs/examples/parameter.md:230-235 does per draw)."""
+    B = 5
+    s = fitz_problem(ra, N=40, t_max=2.0, B=B)
+    sig = 0.05 + 0.1 * np.random.default_rng(1).random((B, 2))
+    Q, R = ra.ibm_init(2.0 / 40, 3, sig)
+    assert R.shape == (B, 2, 3, 3)
+    args = (s["W"], s["x0"], 0.0, 2.0, 40)
+    m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_rodeo, (Q, R), theta=s["theta"])
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_rodeo, (Q, R), theta=s["theta"])
+    assert np.max(np.abs(m - mo)) < 1e-9
+    _vclose(v, vo, 1e-9)
+
+
+@pytest.mark.parametrize("p", [2, 3, 4, 5])
+def test_n_deriv_range(ra, p):
+    s = fitz_problem(ra, N=50, t_max=2.5, sigma=.1, p=p)
+    args = (s["W"], s["x0"], 0.0, 2.5, 50)
+    m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, s["prior"], theta=s["theta"])
+    assert np.max(np.abs(m - mo)) < 1e-8 * max(1.0, np.max(np.abs(mo)))
+    _vclose(v, vo, 1e-7)
+
+
+def test_lorenz_parity_short_horizon(ra):
+    """C3's problem (docs/examples/lorenz.md:56-105) on a short horizon where chaos has not amplified rounding."""
+    theta = np.array([28., 10., 8. / 3.])
+    W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, 4)
+    x0 = init(np.array([-12., -5., 38.]), 0.0, theta=theta)
+    N, t_max = 2000, 2.0
+    prior = ra.ibm_init(t_max / N, 4, np.array([5e7] * 3))
+    m, v = ra.solve_mv(None, ra.ode.lorenz63, W, x0, 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
+    mo, vo = scan.solve_mv(None, odes.lorenz63, W, x0, 0.0, t_max, N, oi.interrogate_kramer, prior, theta=theta)
+    assert np.max(np.abs(m[:, :, 0] - mo[:, :, 0])) < 1e-6
+    assert np.all(np.isfinite(v))
+
+    def lor(X, t):
+        x, y, z = X
+        return [-10 * x + 10 * y, 28 * x - y - x * z, -8. / 3. * z + x * y]
+    exact = odeint(lor, [-12., -5., 38.], np.linspace(0, t_max, N + 1), rtol=1e-11, atol=1e-11)
+    assert np.max(np.abs(m[:, :, 0] - exact)) < 0.1            # solver truncation error at dt = 1e-3 (0.045), not parity
+
+
+def test_higher_order_analytic(ra):
+    """K4 directly on the HIP path: O(h^2) convergence to the analytic solution, and parity with the oracle."""
+    W = np.array([[[0., 0., 1., 0.]]]); x0 = np.array([[-1., 0., 1., 0.]])
+    errs = []
+    for N in (50, 100, 200, 400):
+        prior = ra.ibm_init(10.0 / N, 4, np.array([.001]))
+        m, v = ra.solve_mv(None, ra.ode.higher_order, W, x0, 0.0, 10.0, N, ra.interrogate.interrogate_kramer, prior)
+        errs.append(np.max(np.abs(m[:, 0, 0] - odes.higher_order_exact(np.linspace(0, 10, N + 1)))))
+        if N == 100:
+            mo, vo = scan.solve_mv(None, odes.higher_order, W, x0, 0.0, 10.0, N, oi.interrogate_kramer, prior)
+            assert np.max(np.abs(m - mo)) < 1e-9
+    np.testing.assert_allclose(errs, [6.74e-3, 1.67e-3, 4.17e-4, 1.04e-4], rtol=0.02)
+
+
+def test_fitz_vs_odeint_on_gpu(ra):
+    """K3 (tests/test_fitz.py:17-29) evaluated on the HIP path."""
+    s = fitz_problem(ra)
+    exact = odeint(lambda X, t: [3 * (X[0] - X[0] ** 3 / 3 + X[1]), -(X[0] - .2 + .2 * X[1]) / 3], [-1., 1.],
+                   np.linspace(0, 10, 201), rtol=1e-10, atol=1e-10)
+    args = (s["W"], s["x0"], 0.0, 10.0, 200)
+    m, _ = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_rodeo, s["prior"], theta=s["theta"])
+    assert jg.rel_err(m[:, :, 0], exact) <= 5.0
+    x = ra.solve_sim(0, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_rodeo, s["prior"], theta=s["theta"])
+    assert x.shape == (201, 2, 3) and jg.rel_err(x[:, :, 0], exact) <= 5.0
+
+
+@pytest.mark.parametrize("name", ["rodeo", "kramer"])
+def test_solve_sim_parity(ra, name):
+    """Same Philox stream on both sides -> sample paths agree to rounding (draw parity with JAX: unpinned)."""
+    g, o = _itg(ra, name)
+    B = 9
+    s = fitz_problem(ra, N=80, t_max=4.0, sigma=.1, B=B)
+    args = (s["W"], s["x0"], 0.0, 4.0, 80)
+    x = ra.solve_sim(42, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    xo = scan.solve_sim(42, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    assert x.shape == (B, 81, 2, 3)
+    np.testing.assert_array_equal(x[:, 0], s["x0"])                         # solve.py:196-204
+    assert np.max(np.abs(x - xo)) < 1e-7
+    x2 = ra.solve_sim(43, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    assert np.max(np.abs(x - x2)) > 1e-6                                    # another seed, another path
+
+
+def test_chkrebtii_parity_and_sharding(ra):
+    """C4's combination: solve_sim + interrogate_chkrebtii (docs/examples/parameter.md:331-351)."""
+    g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="standard")
+    o = functools.partial(oi.interrogate_chkrebtii, kalman_type="standard")
+    B = 12
+    s = fitz_problem(ra, N=100, t_max=5.0, sigma=.1, B=B)
+    args = (s["W"], s["x0"], 0.0, 5.0, 100)
+    x = ra.solve_sim(7, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    xo = scan.solve_sim(7, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    assert np.max(np.abs(x - xo)) < 1e-7
+    # sharding invariance: trajectories 4..7 solved alone with traj_offset = 4 give the same draws
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, s["W"], s["x0"][4:8], 0.0, 5.0, 100, g, s["prior"], traj_offset=4,
+                        theta=s["theta"][4:8])
+    plan.sim(7)
+    np.testing.assert_array_equal(plan.x_host(), x[4:8])
+    with pytest.raises(TypeError):                                          # kalman_type must be bound
+        ra.solve_sim(7, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_chkrebtii, s["prior"], theta=s["theta"])
+
+
+def test_solve_sim_law(ra):
+    """Sample mean / variance over many draws match solve_mv's posterior (distributional check of the draws)."""
+    B = 4096
+    s = fitz_problem(ra, N=50, t_max=2.5, sigma=.5)
+    x0 = np.broadcast_to(s["x0"], (B, 2, 3)).copy()
+    args = (s["W"], x0, 0.0, 2.5, 50)
+    xs = ra.solve_sim(11, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_rodeo, s["prior"], theta=s["theta"])
+    m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, 2.5, 50, ra.interrogate.interrogate_rodeo,
+                       s["prior"], theta=s["theta"])
+    var = np.einsum("nbii->nbi", v)
+    z = (xs.mean(0) - m)[1:] / np.sqrt(var[1:] / B)
+    assert np.max(np.abs(z)) < 5.0
+    ratio = xs.var(0)[1:] / var[1:]
+    assert 0.85 < ratio.min() and ratio.max() < 1.15
+
+
+def test_headline_config_full_size_properties(ra):
+    """
+    BASELINE.json config 2 at full size (FN, p=3, N=4000, B=1024, kramer, solve_mv): size-independent properties --
+    trajectory 0 (the unperturbed README problem) matches the oracle and odeint; every trajectory's b-th result equals
+    the same trajectory solved alone (no cross-lane leakage); variances symmetric-PSD and finite; end conditions hold.
+    """
+    B, N = 1024, 4000
+    rng = np.random.default_rng(20240)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.1 * rng.standard_normal((B, 3)))
+    x0v = np.array([-1., 1.]) + 0.1 * rng.standard_normal((B, 2))
+    theta[0] = [0.2, 0.2, 3.0]; x0v[0] = [-1., 1.]
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    x0 = init(x0v, 0.0, theta=theta)
+    prior = ra.ibm_init(0.01, 3, np.array([.1, .1]))
+    m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, W, x0, 0.0, 40.0, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
+    assert m.shape == (B, N + 1, 2, 3) and np.all(np.isfinite(m)) and np.all(np.isfinite(v))
+    np.testing.assert_array_equal(m[:, 0], x0); assert np.all(v[:, 0] == 0)
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, W, x0[0], 0.0, 40.0, N, oi.interrogate_kramer, prior, theta=theta[0])
+    assert np.max(np.abs(m[0] - mo)) < 1e-9
+    _vclose(v[0], vo, 1e-8)
+    exact = odeint(lambda X, t: [3 * (X[0] - X[0] ** 3 / 3 + X[1]), -(X[0] - .2 + .2 * X[1]) / 3], [-1., 1.],
+                   np.linspace(0, 40, N + 1), rtol=1e-10, atol=1e-10)
+    assert np.max(np.abs(m[0, :, :, 0] - exact)) < 1e-4
+    for b in (1, 63, 64, 777, 1023):
+        m1, v1 = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, W, x0[b], 0.0, 40.0, N, ra.interrogate.interrogate_kramer,
+                             prior, theta=theta[b])
+        np.testing.assert_array_equal(m[b], m1); np.testing.assert_array_equal(v[b], v1)
+    asym = np.max(np.abs(v - np.swapaxes(v, -1, -2)))
+    assert asym < 1e-12 * np.max(np.abs(v))
+    assert np.einsum("bnkii->bnki", v).min() >= -1e-18
