@@ -1,0 +1,74 @@
+"""
+N > 1 path on CPU: world_size-2 gloo processes shard a batch of parameter draws, each evaluates its shard (with the
+oracle standing in for the device here -- there is no GPU in this container), and the all-gather of per-draw scalars
+reproduces the single-process result exactly.  Draws are keyed by the global index, so sharding does not change them.
+"""
+import os
+import socket
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+from rodeo_amd import shard as rs
+
+
+def test_partition_covers_everything():
+    for n, g in [(8192, 8), (1000, 3), (5, 8), (0, 2), (7, 1)]:
+        spans = [rs.partition(n, r, g) for r in range(g)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        rs.partition(10, 3, 3)
+    x = np.arange(10)
+    assert np.array_equal(np.concatenate([rs.shard(x, r, 3) for r in range(3)]), x)
+    assert rs.shard(x, 1, 3, batched=False) is x
+
+
+def _logpost_of_shard(lo, hi, seed):
+    """Per-draw scalar of a chkrebtii solve_sim for global draws [lo, hi) (oracle stands in for the GPU on CPU)."""
+    import functools
+    from oracle import scan, odes, priors, interrogations as oi
+    rng = np.random.default_rng(20242)
+    n_tot = 10
+    u = np.array([np.log(.2), np.log(.2), np.log(3.), -1., 1.]) + 0.01 * rng.standard_normal((n_tot, 5))
+    theta = np.exp(u[lo:hi, :3]); x0v = u[lo:hi, 3:5]
+    W, init = priors.first_order_pad(odes.fitzhugh_nagumo, 2, 3)
+    x0 = np.stack([init(x0v[i], 0., theta=theta[i]) for i in range(hi - lo)])
+    prior = priors.ibm_init(0.1, 3, np.array([.1, .1]))
+    itg = functools.partial(oi.interrogate_chkrebtii, kalman_type="standard")
+    x = scan.solve_sim(seed, odes.fitzhugh_nagumo, W, x0, 0., 2., 20, itg, prior, traj_offset=lo, theta=theta)
+    return x[:, -1, 0, 0] + x[:, 10, 1, 0]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = rs.partition(10, rank, world)
+    local = _logpost_of_shard(lo, hi, seed=7)
+    full = rs.gather_scalars(local, 10, rank, world)
+    if rank == 0:
+        q.put(full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single_process(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(full, _logpost_of_shard(0, 10, seed=7))
