@@ -152,14 +152,15 @@ def main():
     kern_ms = {k: float(np.mean(v)) for k, v in acc.items()}
 
     # sanity on the result of the timed computation (cheap): finite, end conditions
-    m_last = plan.mean_state.to_host()[-1]
-    ok = bool(np.all(np.isfinite(m_last)))
+    last = plan.var_state.slice0_host(-1)                      # state at t_max (tile layout: [Sigma | mu] rows)
+    ok = bool(np.all(np.isfinite(last)))
 
     if rank == 0:
         units = N_TRAJ * N_STEPS                                  # trajectory-steps per launch per rank
         a_fwd, a_bwd = D * P * (P + 1) * 8, 2 * D * P * (P + 1) * 8    # write filt | read filt + write smooth
         dom = max(kern_ms, key=kern_ms.get)
         a_dom = a_fwd if dom.startswith("fwd") else a_bwd
+        layout = {0: "batch-minor", 1: "tile3 (3x4 [Sigma|mu] rows per block, 96 B)"}.get(plan.layout, str(plan.layout))
         achieved = a_dom * units / (kern_ms[dom] * 1e-3) / 1e9
         solve_ms = sum(kern_ms.values())
         out = {
@@ -175,7 +176,7 @@ def main():
                                    "solve_mv + interrogate_kramer, kalman_type=standard",
                        "n_traj_per_gpu": N_TRAJ, "n_steps": N_STEPS, "n_block": D, "n_bstate": P,
                        "sharding": f"batch split over {world} rank(s), no data-path collective", "comm": comm,
-                       "result_finite": ok},
+                       "hbm_layout": layout, "result_finite": ok},
             "device_ms_per_step": dev_ms / args.steps,
             "kernels_ms": kern_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

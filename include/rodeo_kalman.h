@@ -63,6 +63,17 @@ extern "C" {
 
 /* flags for rk_solve_cfg.flags */
 #define RK_FLAG_STORE_PRED   1    /* also write the predicted moments (solve.py:93-96 state_pred)            */
+#define RK_FLAG_BATCH_MINOR  2    /* force the batch-minor kernels/layout even where the tile path exists    */
+
+/* which call a layout query refers to */
+#define RK_MODE_FILTER  0
+#define RK_MODE_MV      1
+#define RK_MODE_SIM     2
+
+/* output layouts of the fused solvers (see rk_solve_layout) */
+#define RK_LAYOUT_BATCH_MINOR  0  /* mean_state (N+1, d, p, B), var_state (N+1, d, p, p, B)                  */
+#define RK_LAYOUT_TILE3        1  /* n_bstate = 3 only: var_state holds (N+1, B, d, 3, 4) doubles, row i of a
+                                     block = [Sigma[i][0..2], mu[i]]; mean_state is not used (may be NULL)  */
 
 typedef struct rk_handle_s* rk_handle;
 
@@ -126,8 +137,14 @@ typedef struct {
     double* x_state;        /* (N+1, d, p, B)                                                               */
 } rk_solve_out;
 
-/* bytes of the arrays above for a configuration (any pointer may be NULL) */
-int rk_solve_sizes(const rk_solve_cfg* cfg, size_t* mean_bytes, size_t* var_bytes);
+/* Output layout the fused kernels use for this configuration and call (RK_MODE_*).  The MFMA-tile kernels
+ * (n_bstate = 3, n_bmeas = 1, solve_mv / filter, kramer | schober | rodeo) write RK_LAYOUT_TILE3; everything else
+ * RK_LAYOUT_BATCH_MINOR.  The caller sizes and interprets out->mean_state / var_state accordingly.             */
+int rk_solve_layout(const rk_solve_cfg* cfg, int32_t mode, int32_t* layout);
+/* bytes of the output arrays for a configuration in the given layout (any pointer may be NULL);
+ * RK_LAYOUT_TILE3: *mean_bytes = 0, *var_bytes = ((N+1) * B * d * 12 + 64) * 8 -- the buffer MUST have this size:
+ * the last 64 doubles are a scratch tail that lanes without an output slot store to.                          */
+int rk_solve_sizes(const rk_solve_cfg* cfg, int32_t layout, size_t* mean_bytes, size_t* var_bytes);
 
 /* forward pass only: src/rodeo/solve.py:31-122 (_solve_filter).  out->mean_state/var_state <- filtered. */
 int rk_solve_filter(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out);

@@ -16,6 +16,9 @@ KALMAN_STANDARD, KALMAN_SQRT = 0, 1
 INTERROGATE_RODEO, INTERROGATE_SCHOBER, INTERROGATE_KRAMER, INTERROGATE_CHKREBTII = 0, 1, 2, 3
 RHS_FITZHUGH_NAGUMO, RHS_LORENZ63, RHS_HIGHER_ORDER, RHS_LINEAR_DENSE = 1, 2, 3, 4
 FLAG_STORE_PRED = 1
+FLAG_BATCH_MINOR = 2
+MODE_FILTER, MODE_MV, MODE_SIM = 0, 1, 2
+LAYOUT_BATCH_MINOR, LAYOUT_TILE3 = 0, 1
 COMM_UID_BYTES = 128
 
 
@@ -73,7 +76,8 @@ SIGNATURES = {
     "rk_timer_stop": (C.c_int, [_H, C.POINTER(_D)]),
     "rk_profile_enable": (C.c_int, [_H, C.c_int]),
     "rk_profile_last": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_D), C.POINTER(C.c_int)]),
-    "rk_solve_sizes": (C.c_int, [C.POINTER(SolveCfg), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "rk_solve_layout": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(_I)]),
+    "rk_solve_sizes": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rk_solve_filter": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut)]),
     "rk_solve_mv": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut)]),
     "rk_solve_sim": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut)]),

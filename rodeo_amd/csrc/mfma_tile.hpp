@@ -1,0 +1,45 @@
+// 4x4 fp64 tiles spread over the lanes of a wavefront, multiplied with v_mfma_f64_4x4x4_4b_f64.
+//
+// Why: with one lane per trajectory the N-step recursion is VALU-issue-bound (~335 dependent-ish fp64 ops per step on
+// 16 waves for the headline config).  Spreading each (trajectory, block) state over 16 lanes cuts the per-wave
+// instruction count ~10x, but then every matrix product needs cross-lane operands; the 4-block 4x4x4 fp64 MFMA does
+// that data movement inside the matrix pipe (no DPP / LDS shuffles) at the same FLOP rate as the VALU.
+//
+// Lane map (measured on gfx950, profiles/r01_probe_f64_mfma_layout_and_latency.log):
+//     lane = 16*r + 4*g + c        r = row (0..3), g = tile within the wave (0..3), c = column (0..3)
+//   A operand: lane holds A_g[i = c][k = r]   i.e. a register holding matrix X "in D layout" is read as X^T
+//   B operand: lane holds B_g[k = r][j = c]   (D layout)
+//   C / D    : lane holds D_g[i = r][j = c]   (D layout)
+// so for registers X, Y, Z holding one matrix element per lane in D layout:   MF(X, Y, Z) = X^T Y + Z   per tile.
+// Latency 29 cycles through A/B, 21 through C; issue 16 cycles (profiles/r01_probe2_fp64_valu_mfma_latency.log).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rk {
+
+__device__ __forceinline__ double MF(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// broadcast column 3 of every (r, g) quad to its four lanes
+__device__ __forceinline__ double quad_bcast3(double x) { return dpp64<0xFF>(x); }
+// value held by the same (r, c) lane of tile g-1 / g+1 (cyclic within the 16-lane row)
+__device__ __forceinline__ double from_prev_tile(double x) { return dpp64<0x124>(x); }   // row_ror:4
+__device__ __forceinline__ double from_next_tile(double x) { return dpp64<0x12C>(x); }   // row_ror:12
+
+// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (41 cycles vs ~75 for the IEEE division sequence)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+}  // namespace rk

@@ -12,16 +12,25 @@
 
 namespace rk {
 
+// x / 3, correctly rounded, without the ~12-instruction IEEE division sequence: q = x * RN(1/3) followed by one
+// fused Newton correction with the exact residual (Markstein's division-by-constant; 3 has no all-ones mantissa).
+__device__ __forceinline__ double div3(double x) {
+    const double c = 0.33333333333333331;
+    const double q = x * c;
+    return fma(fma(-3.0, q, x), c, q);
+}
+
 // FitzHugh-Nagumo, README.md:92-99 / docs/examples/parameter.md:60-68.  theta = (a, b, c).
 struct FitzHughNagumo {
     static constexpr int D = 2;
     static constexpr int NTHETA = 3;
+    static constexpr int NDEP = 1;     // f and J depend only on the first NDEP entries X[b][0..NDEP) of every block
     template <int P>
     __device__ __forceinline__ static void f(const double (&X)[D][P], double, const double (&th)[NTHETA],
                                              double (&out)[D]) {
         const double a = th[0], b = th[1], c = th[2];
         const double V = X[0][0], R = X[1][0];
-        out[0] = c * (V - V * V * V / 3 + R);
+        out[0] = c * (V - div3(V * V * V) + R);
         out[1] = -1 / c * (V - a + b * R);
     }
     template <int P>
@@ -42,6 +51,7 @@ struct FitzHughNagumo {
 struct Lorenz63 {
     static constexpr int D = 3;
     static constexpr int NTHETA = 3;
+    static constexpr int NDEP = 1;     // f and J depend only on the first NDEP entries X[b][0..NDEP) of every block
     template <int P>
     __device__ __forceinline__ static void f(const double (&X)[D][P], double, const double (&th)[NTHETA],
                                              double (&out)[D]) {
@@ -69,6 +79,7 @@ struct Lorenz63 {
 struct HigherOrder {
     static constexpr int D = 1;
     static constexpr int NTHETA = 1;   // unused (one dummy slot keeps the array types non-empty)
+    static constexpr int NDEP = 1;
     template <int P>
     __device__ __forceinline__ static void f(const double (&X)[D][P], double t, const double (&)[NTHETA],
                                              double (&out)[D]) {

@@ -10,34 +10,9 @@
 #include "kalman_small.hpp"
 #include "philox.hpp"
 #include "rhs.hpp"
+#include "solve_args.hpp"
 
 namespace rk {
-
-struct SolveArgs {
-    int B, N, D;
-    double t_min, t_max;
-    uint64_t seed, traj_offset;
-    const double *W, *x0, *Q, *R, *theta;
-    int W_b, x0_b, Q_b, R_b, theta_b;
-    double *mean, *var, *mean_pred, *var_pred, *x;
-};
-
-__device__ __forceinline__ double ld(const double* p, size_t e, int batched, int B, int b) {
-    return batched ? p[e * (size_t)B + b] : p[e];
-}
-
-template <int P>
-__device__ __forceinline__ void load_block_consts(const SolveArgs& a, int blk, int b, double (&Q)[P][P],
-                                                  double (&R)[P][P]) {
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const size_t e = ((size_t)blk * P + i) * P + j;
-            Q[i][j] = ld(a.Q, e, a.Q_b, a.B, b);
-            R[i][j] = ld(a.R, e, a.R_b, a.B, b);
-        }
-}
 
 // ---- interrogation of one trajectory (all blocks): src/rodeo/interrogate.py -----------------------------------
 // Produces W_meas = ode_weight + wgt_meas (solve.py:79), mean_meas and var_meas (n_bmeas = 1 -> scalars per block).
@@ -480,15 +455,33 @@ static int launch_itg_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a
     return RK_OK;
 }
 
+// MFMA-tile path (solve_tile3.hip)
+bool tile3_supported(const rk_solve_cfg* c, int mode);
+int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
+
 }  // namespace rk
 
 using namespace rk;
 
 extern "C" {
 
-int rk_solve_sizes(const rk_solve_cfg* c, size_t* mean_bytes, size_t* var_bytes) {
+int rk_solve_layout(const rk_solve_cfg* c, int32_t mode, int32_t* layout) {
+    RK_REQUIRE(c && layout, RK_ERR_INVALID, "rk_solve_layout: null argument");
+    RK_REQUIRE(mode >= RK_MODE_FILTER && mode <= RK_MODE_SIM, RK_ERR_INVALID, "rk_solve_layout: bad mode %d", mode);
+    *layout = tile3_supported(c, mode) ? RK_LAYOUT_TILE3 : RK_LAYOUT_BATCH_MINOR;
+    return RK_OK;
+}
+
+int rk_solve_sizes(const rk_solve_cfg* c, int32_t layout, size_t* mean_bytes, size_t* var_bytes) {
     RK_REQUIRE(c, RK_ERR_INVALID, "rk_solve_sizes: null cfg");
     const size_t m = (size_t)(c->n_steps + 1) * c->n_block * c->n_bstate * (size_t)c->n_traj * sizeof(double);
+    if (layout == RK_LAYOUT_TILE3) {
+        RK_REQUIRE(c->n_bstate == 3, RK_ERR_INVALID, "RK_LAYOUT_TILE3 needs n_bstate = 3");
+        if (mean_bytes) *mean_bytes = 0;
+        if (var_bytes) *var_bytes = ((size_t)(c->n_steps + 1) * c->n_block * (size_t)c->n_traj * 12 + 64) * sizeof(double);
+        return RK_OK;
+    }
+    RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR, RK_ERR_INVALID, "unknown layout %d", layout);
     if (mean_bytes) *mean_bytes = m;
     if (var_bytes) *var_bytes = m * c->n_bstate;
     return RK_OK;
@@ -499,7 +492,9 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     RK_REQUIRE(h, RK_ERR_INVALID, "null handle");
     int rc = check_cfg(c, in);
     if (rc) return rc;
-    RK_REQUIRE(out && out->mean_state && out->var_state, RK_ERR_INVALID, "out->mean_state / var_state must not be NULL");
+    const bool tile = tile3_supported(c, mode);
+    RK_REQUIRE(out && out->var_state && (tile || out->mean_state), RK_ERR_INVALID,
+               "out->mean_state / var_state must not be NULL");
     RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED) || (out->mean_pred && out->var_pred), RK_ERR_INVALID,
                "RK_FLAG_STORE_PRED needs out->mean_pred / var_pred");
     RK_REQUIRE(mode != 2 || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");
@@ -510,6 +505,7 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     h->event_used = 0;
     SolveArgs a;
     make_args(c, in, out, a);
+    if (tile) return tile3_solve(h, c, a, out->var_state, mode);
     rc = small_forward(h, c, a);
     if (rc) return rc;
     if (mode == 1) rc = small_backward<false>(h, c, a);

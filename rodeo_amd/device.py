@@ -43,8 +43,8 @@ class Device:
         return buf.value.decode()
 
     # ---- arrays ----
-    def empty(self, shape, dtype=np.float64):
-        return DeviceArray(self, tuple(int(s) for s in shape), np.dtype(dtype))
+    def empty(self, shape, dtype=np.float64, pad_bytes=0):
+        return DeviceArray(self, tuple(int(s) for s in shape), np.dtype(dtype), pad_bytes)
 
     def zeros(self, shape, dtype=np.float64):
         a = self.empty(shape, dtype)
@@ -92,15 +92,25 @@ class Device:
 class DeviceArray:
     """A device buffer of a given shape/dtype (C-contiguous).  Freed when garbage-collected."""
 
-    def __init__(self, dev, shape, dtype):
+    def __init__(self, dev, shape, dtype, pad_bytes=0):
         self.dev, self.shape, self.dtype = dev, shape, dtype
         self.nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-        self.ptr = dev.alloc(self.nbytes) if self.nbytes else C.c_void_p()
+        self.ptr = dev.alloc(self.nbytes + pad_bytes) if self.nbytes else C.c_void_p()
 
     def to_host(self):
         out = np.empty(self.shape, self.dtype)
         if self.nbytes:
             _lib.check(self.dev.lib.rk_d2h(self.dev.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def slice0_host(self, i):
+        """Download only the i-th slice along the leading axis."""
+        out = np.empty(self.shape[1:], self.dtype)
+        nb = out.nbytes
+        i = i % self.shape[0]
+        if nb:
+            src = C.c_void_p(self.ptr.value + i * nb)
+            _lib.check(self.dev.lib.rk_d2h(self.dev.h, out.ctypes.data_as(C.c_void_p), src, nb))
         return out
 
     def batch_first(self):

@@ -22,7 +22,7 @@ import ctypes as C
 import functools
 import numpy as np
 from . import _lib, interrogate as _itg
-from .device import default_device, batch_minor
+from .device import default_device, batch_minor as _bm
 from .ode import DeviceODE
 
 _KALMAN = {"standard": _lib.KALMAN_STANDARD, "square-root": _lib.KALMAN_SQRT}
@@ -63,7 +63,7 @@ class SolvePlan:
     """
 
     def __init__(self, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars,
-                 kalman_type="standard", device=None, traj_offset=0, store_pred=False, **params):
+                 kalman_type="standard", device=None, traj_offset=0, store_pred=False, batch_minor=False, **params):
         if kalman_type not in _KALMAN:
             raise NotImplementedError                    # src/rodeo/solve.py:142-143, 240-241
         if not isinstance(ode_fun, DeviceODE):
@@ -101,14 +101,15 @@ class SolvePlan:
                              f"but ode_weight has ({d}, {m})")
         self.B, self.N, self.d, self.p, self.m = B, int(n_steps), d, p, m
         dev = self.dev
-        self._W = dev.to_device(batch_minor(W, W.ndim == 4))
-        self._x0 = dev.to_device(batch_minor(x0, x0.ndim == 3))
-        self._Q = dev.to_device(batch_minor(Q, Q.ndim == 4))
-        self._R = dev.to_device(batch_minor(R, R.ndim == 4))
-        self._theta = dev.to_device(batch_minor(theta, Bt is not None)) if theta.size else None
+        self._W = dev.to_device(_bm(W, W.ndim == 4))
+        self._x0 = dev.to_device(_bm(x0, x0.ndim == 3))
+        self._Q = dev.to_device(_bm(Q, Q.ndim == 4))
+        self._R = dev.to_device(_bm(R, R.ndim == 4))
+        self._theta = dev.to_device(_bm(theta, Bt is not None)) if theta.size else None
         self.cfg = _lib.SolveCfg(n_traj=B, n_steps=self.N, n_block=d, n_bstate=p, n_bmeas=m, rhs_id=ode_fun.rhs_id,
                                  interrogate=itg_id, kalman_type=_KALMAN[kalman_type], n_theta=ode_fun.n_theta,
-                                 flags=_lib.FLAG_STORE_PRED if store_pred else 0, t_min=float(t_min),
+                                 flags=(_lib.FLAG_STORE_PRED if store_pred else 0) |
+                                 (_lib.FLAG_BATCH_MINOR if batch_minor else 0), t_min=float(t_min),
                                  t_max=float(t_max), seed=0, traj_offset=int(traj_offset))
         self.inp = _lib.SolveIn(
             ode_weight=self._W.ptr, ode_weight_batched=int(W.ndim == 4),
@@ -116,32 +117,49 @@ class SolvePlan:
             prior_weight=self._Q.ptr, prior_weight_batched=int(Q.ndim == 4),
             prior_var=self._R.ptr, prior_var_batched=int(R.ndim == 4),
             theta=self._theta.ptr if self._theta is not None else None, theta_batched=int(Bt is not None))
-        N1 = self.N + 1
-        self.mean_state = dev.empty((N1, d, p, B))
-        self.var_state = dev.empty((N1, d, p, p, B))
-        self.mean_pred = dev.empty((N1, d, p, B)) if store_pred else None
-        self.var_pred = dev.empty((N1, d, p, p, B)) if store_pred else None
-        self.x_state = None
-        self._out = _lib.SolveOut(mean_state=self.mean_state.ptr, var_state=self.var_state.ptr,
-                                  mean_pred=self.mean_pred.ptr if store_pred else None,
-                                  var_pred=self.var_pred.ptr if store_pred else None, x_state=None)
+        self._store_pred = store_pred
+        self.layout = None                 # layout of the last launch (RK_LAYOUT_*)
+        self._bufs = {}                    # layout -> (mean_state, var_state)
+        self.mean_state = self.var_state = self.mean_pred = self.var_pred = self.x_state = None
+        self._out = _lib.SolveOut()
+
+    def _prepare_out(self, mode):
+        """Ask the library which layout this call uses and (once) allocate the outputs for it."""
+        lay = C.c_int32(0)
+        _lib.check(self.dev.lib.rk_solve_layout(C.byref(self.cfg), mode, C.byref(lay)))
+        lay = lay.value
+        dev, N1, d, p, B = self.dev, self.N + 1, self.d, self.p, self.B
+        if lay not in self._bufs:
+            if lay == _lib.LAYOUT_TILE3:
+                self._bufs[lay] = (None, dev.empty((N1, B, d, 3, 4), pad_bytes=64 * 8))    # + scratch tail (ABI)
+            else:
+                self._bufs[lay] = (dev.empty((N1, d, p, B)), dev.empty((N1, d, p, p, B)))
+        self.layout = lay
+        self.mean_state, self.var_state = self._bufs[lay]
+        if self._store_pred and self.mean_pred is None:
+            self.mean_pred, self.var_pred = dev.empty((N1, d, p, B)), dev.empty((N1, d, p, p, B))
+        if mode == _lib.MODE_SIM and self.x_state is None:
+            self.x_state = dev.empty((N1, d, p, B))
+        self._out = _lib.SolveOut(
+            mean_state=self.mean_state.ptr if self.mean_state is not None else None, var_state=self.var_state.ptr,
+            mean_pred=self.mean_pred.ptr if self.mean_pred is not None else None,
+            var_pred=self.var_pred.ptr if self.var_pred is not None else None,
+            x_state=self.x_state.ptr if self.x_state is not None else None)
 
     # ---- launches (asynchronous) ----
-    def _call(self, fn, key):
+    def _call(self, fn, key, mode):
+        self._prepare_out(mode)
         self.cfg.seed = _seed(key)
         _lib.check(fn(self.dev.h, C.byref(self.cfg), C.byref(self.inp), C.byref(self._out)))
 
     def filter(self, key=None):
-        self._call(self.dev.lib.rk_solve_filter, key)
+        self._call(self.dev.lib.rk_solve_filter, key, _lib.MODE_FILTER)
 
     def mv(self, key=None):
-        self._call(self.dev.lib.rk_solve_mv, key)
+        self._call(self.dev.lib.rk_solve_mv, key, _lib.MODE_MV)
 
     def sim(self, key=None):
-        if self.x_state is None:
-            self.x_state = self.dev.empty((self.N + 1, self.d, self.p, self.B))
-            self._out.x_state = self.x_state.ptr
-        self._call(self.dev.lib.rk_solve_sim, key)
+        self._call(self.dev.lib.rk_solve_sim, key, _lib.MODE_SIM)
 
     def sync(self):
         self.dev.sync()
@@ -152,6 +170,11 @@ class SolvePlan:
         return a if self.batched else a[0]
 
     def state_host(self):
+        """(mean, var) of the last filter() / mv() in the reference layout (views of one download, no transposes)."""
+        if self.layout == _lib.LAYOUT_TILE3:
+            t = np.moveaxis(self.var_state.to_host(), 1, 0)         # (B, N+1, d, 3, 4): rows [Sigma | mu]
+            mean, var = t[..., 3], t[..., :3]
+            return (mean, var) if self.batched else (mean[0], var[0])
         return self._host(self.mean_state), self._host(self.var_state)
 
     def pred_host(self):
