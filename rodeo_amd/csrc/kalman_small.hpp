@@ -40,7 +40,7 @@ __device__ __forceinline__ void update_block_m1(const double (&W)[P], double a, 
     const double Smm = dot<P>(WS, W) + V;
 #pragma unroll
     for (int i = 0; i < P; ++i) SW[i] = dot<P>(Sp[i], W);
-    const double rS = 1.0 / Smm;
+    const double rS = fast_rcp(Smm);
     const double innov = 0.0 - yhat;
 #pragma unroll
     for (int i = 0; i < P; ++i) {

@@ -7,6 +7,16 @@
 
 namespace rk {
 
+// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (~41 cycles and 5 instructions instead of the ~12-instruction IEEE
+// division sequence; measured in profiles/r01_probe2_fp64_valu_mfma_latency.log).  x = 0 / inf / NaN give NaN or inf,
+// which propagate silently like the reference's singular solves.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // C = A (RxK) * B (KxC)
 template <int R, int K, int C>
 __device__ __forceinline__ void mm(const double (&A)[R][K], const double (&B)[K][C], double (&out)[R][C]) {
@@ -90,7 +100,7 @@ __device__ __forceinline__ void lu_solve(double (&A)[P][P], double (&B)[P][NR]) 
                 B[i][j] = sw ? t : B[i][j];
             }
         }
-        rpiv[k] = 1.0 / A[k][k];
+        rpiv[k] = fast_rcp(A[k][k]);
 #pragma unroll
         for (int i = k + 1; i < P; ++i) {
             const double l = A[i][k] * rpiv[k];
@@ -128,7 +138,7 @@ __device__ __forceinline__ void psd_factor(const double (&A)[P][P], double (&L)[
         for (int k = 0; k < j; ++k) d = fma(-L[j][k], L[j][k], d);
         const bool ok = d > 0.0;
         const double dj = sqrt(ok ? d : 1.0);
-        const double rdj = 1.0 / dj;
+        const double rdj = fast_rcp(dj);
         L[j][j] = ok ? dj : 0.0;
 #pragma unroll
         for (int i = j + 1; i < P; ++i) {

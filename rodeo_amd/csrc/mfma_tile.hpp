@@ -14,6 +14,7 @@
 // Latency 29 cycles through A/B, 21 through C; issue 16 cycles (profiles/r01_probe2_fp64_valu_mfma_latency.log).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "linalg_small.hpp"
 
 namespace rk {
 
@@ -28,18 +29,22 @@ __device__ __forceinline__ double dpp64(double x) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// DPP move restricted to the banks (= tiles g, 4 lanes each) in BANK_MASK; other lanes keep `old`
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp64_banks(double old, double x) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, BANK_MASK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+// For n_block = 2 (tiles g = 0,1 and 2,3 are the two blocks of one trajectory): the value of block 0 / block 1 of
+// this lane's trajectory, given each tile's own value x.  One masked DPP move per 32-bit half, no selects.
+__device__ __forceinline__ double pair_block0(double x) { return dpp64_banks<0x124, 0xA>(x, x); }   // odd g <- g-1
+__device__ __forceinline__ double pair_block1(double x) { return dpp64_banks<0x12C, 0x5>(x, x); }   // even g <- g+1
+
 // broadcast column 3 of every (r, g) quad to its four lanes
 __device__ __forceinline__ double quad_bcast3(double x) { return dpp64<0xFF>(x); }
 // value held by the same (r, c) lane of tile g-1 / g+1 (cyclic within the 16-lane row)
 __device__ __forceinline__ double from_prev_tile(double x) { return dpp64<0x124>(x); }   // row_ror:4
 __device__ __forceinline__ double from_next_tile(double x) { return dpp64<0x12C>(x); }   // row_ror:12
-
-// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (41 cycles vs ~75 for the IEEE division sequence)
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
 
 }  // namespace rk

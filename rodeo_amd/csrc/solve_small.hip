@@ -478,7 +478,10 @@ int rk_solve_sizes(const rk_solve_cfg* c, int32_t layout, size_t* mean_bytes, si
     if (layout == RK_LAYOUT_TILE3) {
         RK_REQUIRE(c->n_bstate == 3, RK_ERR_INVALID, "RK_LAYOUT_TILE3 needs n_bstate = 3");
         if (mean_bytes) *mean_bytes = 0;
-        if (var_bytes) *var_bytes = ((size_t)(c->n_steps + 1) * c->n_block * (size_t)c->n_traj * 12 + 64) * sizeof(double);
+        if (var_bytes) {
+            const size_t n_tiles = (size_t)c->n_block * (size_t)c->n_traj;
+            *var_bytes = ((size_t)(c->n_steps + 1) * n_tiles * 12 + ((n_tiles + 3) / 4) * 64) * sizeof(double);
+        }
         return RK_OK;
     }
     RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR, RK_ERR_INVALID, "unknown layout %d", layout);

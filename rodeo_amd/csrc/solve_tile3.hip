@@ -64,30 +64,35 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     // per-lane constants in D layout
     const double Qt = in3 ? ld(a.Q, ((size_t)blk * P + c) * P + r, a.Q_b, a.B, b) : ((r == 3 && c == 3) ? 1.0 : 0.0);
     const double Rt = in3 ? ld(a.R, ((size_t)blk * P + r) * P + c, a.R_b, a.B, b) : 0.0;
-    const double Wr = r < 3 ? ld(a.W, (size_t)blk * P + r, a.W_b, a.B, b) : 0.0;          // row form
+    const double Wr = r < 3 ? ld(a.W, (size_t)blk * P + r, a.W_b, a.B, b) : 0.0;          // W[k] at row k (all columns)
     const double Y0 = r < 3 ? ld(a.Q, ((size_t)blk * P + 0) * P + r, a.Q_b, a.B, b) : 0.0; // Q[0][k] at row k
+    const double E0 = r == 0 ? 1.0 : 0.0;                                                  // selects row 0
+    const double e3r = r == 3 ? 1.0 : 0.0;
+    const double m3 = r == 3 ? 0.0 : 1.0;
     double th[RHS::NTHETA];
 #pragma unroll
     for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
 
     // M_0 = [0 | ode_init ; 0 1]   (solve.py:53-54)
     double M = r < 3 ? (c == 3 ? ld(a.x0, (size_t)blk * P + r, a.x0_b, a.B, b) : 0.0) : (c == 3 ? 1.0 : 0.0);
-    // lanes without a slot in the 3 x 4 tile (row 3, or tiles past the end) store to the 64-double scratch tail of the
-    // buffer instead of being masked off: no exec-mask branch in the time loop
+    // lanes without a slot in the 3 x 4 tile (row 3, or tiles past the end) store to this wave's 64-double slice of the
+    // scratch tail of the buffer instead of being masked off: no exec-mask branch in the time loop
     const bool st = tc.valid && r < 3;
     const size_t tstride_all = (size_t)n_tiles * TILE_DOUBLES;
     double* out = st ? tiles + (size_t)tc.tau * TILE_DOUBLES + r * 4 + c
-                     : tiles + (size_t)(a.N + 1) * tstride_all + threadIdx.x;
+                     : tiles + (size_t)(a.N + 1) * tstride_all + (size_t)blockIdx.x * 64 + threadIdx.x;
     const size_t tstride = st ? tstride_all : 0;
     out[0] = M;
 
     for (int n = 0; n < a.N; ++n) {
-        // predict, and row 0 of Q~ M broadcast to all rows (its column 3 is mu-_0)
+        // ---- predict (standard.py:57-59): U = (Q~ M)^T, M- = Q~ M Q~^T + R~; B0 = row 0 of Q~ M in every row ----
+        // (a 4x4x4 fp64 MFMA blocks this wave's issue for ~17 cycles = 4 fp64 VALU ops, and nothing overlaps it --
+        //  profiles/r01_probe3_mfma_valu_serialize.log -- so the step is written with the fewest MFMAs: six)
         const double U = MF(M, Qt, 0.0);
         const double B0 = MF(Y0, M, 0.0);
         const double Mp = MF(U, Qt, Rt);
-        const double v_own = quad_bcast3(B0);
-        // interrogation (interrogate.py): f and the block-diagonal Jacobian at mu-
+        // ---- interrogation (interrogate.py): f and the block-diagonal Jacobian at mu- ----
+        const double v_own = quad_bcast3(B0);          // mu-_0 of this tile's block, in all 16 lanes
         double X[D][P];
 #pragma unroll
         for (int bb = 0; bb < D; ++bb)
@@ -96,10 +101,8 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         if constexpr (D == 1) {
             X[0][0] = v_own;
         } else {
-            const double v_prev = from_prev_tile(v_own), v_next = from_next_tile(v_own);
-            const double v_oth = blk == 0 ? v_next : v_prev;
-            X[0][0] = blk == 0 ? v_own : v_oth;
-            X[1][0] = blk == 0 ? v_oth : v_own;
+            X[0][0] = pair_block0(v_own);
+            X[1][0] = pair_block1(v_own);
         }
         const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
         double f[D], J[D][P];
@@ -115,14 +118,13 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         double fb = f[0], J0 = J[0][0];
         if constexpr (D == 2) { fb = blk == 0 ? f[0] : f[1]; J0 = blk == 0 ? J[0][0] : J[1][0]; }
         // X_w[k] (row form): W~_k = W_k - J_k for k < 3 (solve.py:79, interrogate.py:80), a = -f + J mu- at k = 3
-        const double a_meas = fma(J0, v_own, -fb);
-        const double Xw = r == 0 ? Wr - J0 : (r == 3 ? a_meas : Wr);
-        // update
-        const double WS = MF(Xw, Mp, 0.0);
-        const double Zr = MF(Mp, Xw, 0.0);
-        const double Z0 = r == 3 ? 0.0 : Zr;
+        const double a_meas = fma(J0, v_own, -fb);                  // mean_meas (interrogate.py:81-82)
+        const double Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));       // rows: W_0 - J0, W_1, W_2, a
+        // ---- update (standard.py:93-102) ----
+        const double WS = MF(Xw, Mp, 0.0);                          // [W~ Sigma- | W~ mu- + a]   (column form)
+        const double Z0 = MF(Mp, Xw, 0.0) * m3;                     // Sigma- W~^T (row form), 0 in row 3
         double S = MF(Z0, Xw, 0.0);
-        if constexpr (ITG == RK_INTERROGATE_RODEO) S = S + S;      // var_meas = W Sigma- W^T (interrogate.py:110-113)
+        if constexpr (ITG == RK_INTERROGATE_RODEO) S = S + S;       // var_meas = W Sigma- W^T (interrogate.py:110-113)
         const double K = Z0 * fast_rcp(S);
         M = fma(-K, WS, Mp);
         out += tstride;
@@ -130,36 +132,44 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     }
 }
 
-// ---- backward: producer / consumer -----------------------------------------------------------------------------
+// ---- backward: one consumer wave + two producer waves per 4 tiles ----------------------------------------------
+// Time runs in "ticks" separated by workgroup barriers; in tick t the consumer smooths chunk t (16 steps) while
+// the producers prepare later chunks.  Producer p owns the chunks ch = p (mod 2); its work on chunk ch is split in
+// two phases, A in tick ch-2 (prefetch + predict + T) and B in tick ch-1 (pivoted LU + LDS writes), so that each
+// producer has two ticks per chunk and the two producers are always in opposite phases.  Chunk ch is handed over in
+// LDS buffer ch & 1 (written during tick ch-1, read during tick ch).
 constexpr int CHUNK = 16;                       // time steps per hand-off
-constexpr int SLOT = 3 * 16;                    // doubles per (step, tile): M_f, M-, G~^T tiles
+constexpr int ITEM_BYTES = 3 * 128;              // per (step, tile): M-, G~^T, M_f tiles of 16 doubles
+constexpr int BUF_BYTES = CHUNK * 4 * ITEM_BYTES;   // 24 KiB
 
-__device__ __forceinline__ int lds_off(int s, int g, int which, int idx) {
+// byte offset inside a buffer of element idx (= 4 r + c) of tile `which` of item (s, g); the XOR swizzle makes the
+// producer's 64 lanes (one item each, 256 B apart) hit distinct banks
+__device__ __forceinline__ int lds_byte(int s, int g, int which, int idx) {
     const int item = s * 4 + g;
-    return (item * 3 + which) * 16 + (idx ^ (item & 15));      // XOR swizzle: conflict-free producer writes
+    return item * ITEM_BYTES + which * 128 + ((idx ^ (item & 15)) << 3);
 }
 
-__global__ void __launch_bounds__(128) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D) {
+__global__ void __launch_bounds__(192) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D, int dbg) {
     constexpr int P = 3;
-    __shared__ double lds[2][CHUNK * 4 * SLOT];
+    __shared__ __attribute__((aligned(16))) char lds_raw[2 * BUF_BYTES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * TILE_DOUBLES;
-    const int n_back = a.N - 1;                                   // steps n = N-1 .. 1
-    const int n_chunks = (n_back + CHUNK - 1) / CHUNK;
+    const int n_chunks = (a.N - 1 + CHUNK - 1) / CHUNK;            // steps n = N-1 .. 1
+    // this workgroup's 64-double slice of the scratch tail (row 3 of its tiles: e_3)
+    double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)blockIdx.x * 64;
 
-    // constant entries of the hand-off tiles (row 3 = e_3, zero padding) are written once
-    for (int i = threadIdx.x; i < 2 * CHUNK * 4 * SLOT; i += 128) {
-        const int buf = i / (CHUNK * 4 * SLOT), rem = i % (CHUNK * 4 * SLOT);
-        const int item = rem / SLOT, which = (rem % SLOT) / 16, idx = rem % 16;
-        const int rr = idx >> 2, cc = idx & 3;
-        const double v = (rr == 3 && cc == 3) ? 1.0 : 0.0;
-        lds[buf][(item * 3 + which) * 16 + (idx ^ (item & 15))] = v;
+    // constant entries of the hand-off tiles (row 3 = e_3; column 3 of G~^T = e_3) are written once
+    for (int i = threadIdx.x; i < 2 * 64 * 3 * 16; i += 192) {
+        const int idx = i & 15, which = (i >> 4) % 3, item = ((i >> 4) / 3) & 63, buf = i / (64 * 3 * 16);
+        const double v = (idx == 15) ? 1.0 : 0.0;
+        *(double*)(lds_raw + buf * BUF_BYTES + lds_byte(item >> 2, item & 3, which, idx)) = v;
     }
     __syncthreads();
 
-    if (wave == 1) {
-        // ---------------- producer: one lane per (step-in-chunk, tile) ----------------
+    if (wave >= 1) {
+        // ---------------- producers: one lane per (step-in-chunk, tile) ----------------
+        const int p = wave - 1;
         const int s = lane >> 2, g = lane & 3;
         int tau = blockIdx.x * 4 + g;
         if (tau >= n_tiles) tau = n_tiles - 1;
@@ -167,46 +177,69 @@ __global__ void __launch_bounds__(128) bwd_mv_tile3_kernel(SolveArgs a, double* 
         double Q[P][P], R[P][P];
         load_block_consts<P>(a, blk, b, Q, R);
         const double* tin = tiles + (size_t)tau * TILE_DOUBLES;
-        double cur[TILE_DOUBLES], nxt[TILE_DOUBLES];
+        int woff[12];                                              // LDS byte offsets of the 12 slots this lane writes
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) woff[i * 4 + j] = lds_byte(s, g, 0, i * 4 + j);
+        // filt tiles of this producer's chunks are fetched two own chunks (= four ticks) ahead into two statically
+        // named register buffers (global latency under load is longer than one tick)
+        double bufE[TILE_DOUBLES], bufO[TILE_DOUBLES];
         auto fetch = [&](int ch, double (&dst)[TILE_DOUBLES]) {
             int n = a.N - 1 - ch * CHUNK - s;
-            n = n < 1 ? 1 : n;                                   // clamped loads are never used (n >= 1 check below)
+            n = n < 1 ? 1 : n;                                   // clamped loads are never used
             const double* in = tin + (size_t)n * tstride;
 #pragma unroll
             for (int i = 0; i < TILE_DOUBLES; ++i) dst[i] = in[i];
         };
-        fetch(0, cur);
-        for (int ch = 0; ch <= n_chunks; ++ch) {
-            if (ch + 1 < n_chunks) fetch(ch + 1, nxt);           // prefetch the next chunk under this chunk's compute
-            if (ch < n_chunks) {
-                const int n = a.N - 1 - ch * CHUNK - s;
-                if (n >= 1) {
-                    double mf[P], Sf[P][P];
+        if (p < n_chunks) fetch(p, bufE);
+        if (p + 2 < n_chunks) fetch(p + 2, bufO);
+        double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P];
+        auto phaseA = [&](int chA, double (&buf)[TILE_DOUBLES]) {
 #pragma unroll
-                    for (int i = 0; i < P; ++i) {
+            for (int i = 0; i < P; ++i) {
 #pragma unroll
-                        for (int j = 0; j < P; ++j) Sf[i][j] = cur[i * 4 + j];
-                        mf[i] = cur[i * 4 + 3];
-                    }
-                    double mp[P], Sp[P][P], T[P][P], G[P][P];
-                    predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]
-                    smooth_gain<P>(Q, Sf, Sp, T, G);                 // standard.py:175-176 (pivoted LU)
-                    double* o = lds[ch & 1];
+                for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
+                mf[i] = buf[i * 4 + 3];
+            }
+            if (chA + 4 < n_chunks) fetch(chA + 4, buf);         // refill this buffer for the chunk after next
+            __builtin_amdgcn_sched_barrier(0);
+            predict_block<P>(Q, R, mf, Sf, mp, Sp);              // pred[n+1] from filt[n]   (standard.py:57-59)
+            mm_nt<P, P, P>(Sf, Q, T);                            // T = Sigma_f Q^T          (standard.py:175)
+        };
+        for (int t = -2; t < n_chunks; ++t) {
+            const int chA = t + 2, chB = t + 1;
+            if ((chA & 1) == p) {
+                // ---- phase A of chunk chA: (re)fill the fetch buffer, predict, T ----
+                if (chA < n_chunks && !(dbg & 1)) {
+                    if ((chA >> 1) & 1) phaseA(chA, bufO); else phaseA(chA, bufE);
+                }
+            } else {
+                // ---- phase B of chunk chB: G = solve(Sigma-, T^T)^T (standard.py:176), hand-off ----
+                if (chB >= 0 && chB < n_chunks && !(dbg & 1)) {
+                    double A[P][P], X[P][P];
 #pragma unroll
-                    for (int i = 0; i < P; ++i) {
+                    for (int i = 0; i < P; ++i)
 #pragma unroll
-                        for (int j = 0; j < P; ++j) {
-                            o[lds_off(s, g, 0, i * 4 + j)] = Sf[i][j];
-                            o[lds_off(s, g, 1, i * 4 + j)] = Sp[i][j];
-                            o[lds_off(s, g, 2, i * 4 + j)] = G[j][i];      // G~^T
+                        for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
+                    lu_solve<P, P>(A, X);                            // X = G^T
+                    const int n = a.N - 1 - chB * CHUNK - s;
+                    if (n >= 1) {
+                        char* o = lds_raw + (chB & 1) * BUF_BYTES;
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+#pragma unroll
+                            for (int j = 0; j < P; ++j) {
+                                *(double*)(o + woff[i * 4 + j]) = Sp[i][j];             // M-   (which = 0)
+                                *(double*)(o + woff[i * 4 + j] + 128) = X[i][j];        // G~^T (which = 1)
+                                *(double*)(o + woff[i * 4 + j] + 256) = Sf[i][j];       // M_f  (which = 2)
+                            }
+                            *(double*)(o + woff[i * 4 + 3]) = mp[i];
+                            *(double*)(o + woff[i * 4 + 3] + 256) = mf[i];
                         }
-                        o[lds_off(s, g, 0, i * 4 + 3)] = mf[i];
-                        o[lds_off(s, g, 1, i * 4 + 3)] = mp[i];
                     }
                 }
             }
-#pragma unroll
-            for (int i = 0; i < TILE_DOUBLES; ++i) cur[i] = nxt[i];
             __syncthreads();
         }
     } else {
@@ -214,32 +247,57 @@ __global__ void __launch_bounds__(128) bwd_mv_tile3_kernel(SolveArgs a, double* 
         const TileCoord tc = tile_coord<1>(blockIdx.x, lane, n_tiles);      // (b, blk) not needed here
         const int r = tc.r, g = tc.g, c = tc.c, idx = r * 4 + c;
         const bool st = tc.valid && r < 3;
-        // non-storing lanes write to the scratch tail (stride 0) instead of being masked off
-        double* base = st ? tiles + (size_t)tc.tau * TILE_DOUBLES + idx : tiles + (size_t)(a.N + 1) * tstride + lane;
+        // lanes without a slot (row 3, tiles past the end) read and write the scratch tail with stride 0: row 3 of
+        // every tile is e_3 there (stored by the forward kernel and re-stored here), so no masking is needed
+        double* base = st ? tiles + (size_t)tc.tau * TILE_DOUBLES + idx : dump + lane;
         const size_t ostride = st ? tstride : 0;
-        // carry = filt[N]  (solve.py:279-282); row 3 = e_3
-        double Ms = r < 3 ? tiles[(size_t)a.N * tstride + (size_t)tc.tau * TILE_DOUBLES + idx] : (c == 3 ? 1.0 : 0.0);
-        __syncthreads();                                              // chunk 0 produced
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const double* in = lds[ch & 1];
-            const int n_hi = a.N - 1 - ch * CHUNK;
+        int roff[4];                                                // per-lane LDS byte offsets for s & 3 = 0..3
+#pragma unroll
+        for (int k = 0; k < 4; ++k) roff[k] = lds_byte(k, g, 0, idx) - k * 4 * ITEM_BYTES;
+        double Ms = base[(size_t)a.N * ostride];                    // carry = filt[N]  (solve.py:279-282)
+        const long long stamp0 = (dbg & 4) ? __builtin_amdgcn_s_memtime() : 0;     // diagnostic build path only
+        __syncthreads();                                            // tick -2
+        __syncthreads();                                            // tick -1: chunk 0 is in LDS
+        for (int t = 0; t < n_chunks; ++t) {
+            const char* in = lds_raw + (t & 1) * BUF_BYTES;
+            const int n_hi = a.N - 1 - t * CHUNK;
             const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CHUNK ? CHUNK : n_hi);   // steps n_hi .. n_hi-cnt+1
             double* o = base + (size_t)n_hi * ostride;
-            double Mf = in[lds_off(0, g, 0, idx)], Mp = in[lds_off(0, g, 1, idx)], Gt = in[lds_off(0, g, 2, idx)];
-            for (int s = 0; s < cnt; ++s) {
-                // software pipeline: next step's hand-off tiles are read from LDS under this step's MFMAs
-                const int sn = s + 1 < CHUNK ? s + 1 : s;
-                const double nMf = in[lds_off(sn, g, 0, idx)], nMp = in[lds_off(sn, g, 1, idx)],
-                             nGt = in[lds_off(sn, g, 2, idx)];
-                const double Dm = Ms - Mp;
-                const double V1 = MF(Dm, Gt, 0.0);                    // (G~ D)^T
-                Ms = MF(V1, Gt, Mf);                                  // G~ D G~^T + M_f   (standard.py:213-216)
-                o[0] = Ms;
-                o -= ostride;
-                Mf = nMf; Mp = nMp; Gt = nGt;
+            if (!(dbg & 2)) {
+                if (cnt == CHUNK) {
+                    // full chunk, branch-free: all 48 hand-off values are read from LDS up front (immediate offsets),
+                    // then the 16-step dependent chain  D = Ms - M- ; V = MF(D, G~^T) ; Ms = MF(V, G~^T, M_f)
+                    double Mp[CHUNK], Gt[CHUNK], Mf[CHUNK];
+#pragma unroll
+                    for (int s = 0; s < CHUNK; ++s) {
+                        const char* q = in + roff[s & 3] + s * 4 * ITEM_BYTES;
+                        Mp[s] = *(const double*)(q);
+                        Gt[s] = *(const double*)(q + 128);
+                        Mf[s] = *(const double*)(q + 256);
+                    }
+#pragma unroll
+                    for (int s = 0; s < CHUNK; ++s) {
+                        const double Dm = Ms - Mp[s];
+                        const double V1 = MF(Dm, Gt[s], 0.0);           // (G~ D)^T
+                        Ms = MF(V1, Gt[s], Mf[s]);                      // G~ D G~^T + M_f   (standard.py:213-216)
+                        o[0] = Ms;
+                        o -= ostride;
+                    }
+                } else {
+                    for (int s = 0; s < cnt; ++s) {
+                        const char* q = in + lds_byte(s, g, 0, idx);
+                        const double Mp = *(const double*)(q), Gt = *(const double*)(q + 128), Mf = *(const double*)(q + 256);
+                        const double V1 = MF(Ms - Mp, Gt, 0.0);
+                        Ms = MF(V1, Gt, Mf);
+                        o[0] = Ms;
+                        o -= ostride;
+                    }
+                }
             }
             __syncthreads();
         }
+        if ((dbg & 4) && blockIdx.x == 0 && lane == 3)      // shader cycles of the whole consumer loop -> scratch tail
+            dump[lane] = (double)(__builtin_amdgcn_s_memtime() - stamp0);
     }
 }
 
@@ -282,7 +340,7 @@ int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     else rc = launch_fwd_tile<HigherOrder>(h, c, a, tiles);
     if (rc || mode == 0 || a.N < 2) return rc;
     LaunchTimer t(h, "bwd_mv_tile3_kernel");
-    hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(128), 0, h->stream, a, tiles, a.D);
+    hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(192), 0, h->stream, a, tiles, a.D, (c->flags >> 16) & 7);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

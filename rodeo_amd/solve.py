@@ -131,7 +131,9 @@ class SolvePlan:
         dev, N1, d, p, B = self.dev, self.N + 1, self.d, self.p, self.B
         if lay not in self._bufs:
             if lay == _lib.LAYOUT_TILE3:
-                self._bufs[lay] = (None, dev.empty((N1, B, d, 3, 4), pad_bytes=64 * 8))    # + scratch tail (ABI)
+                mb, vb = C.c_size_t(0), C.c_size_t(0)
+                _lib.check(dev.lib.rk_solve_sizes(C.byref(self.cfg), lay, C.byref(mb), C.byref(vb)))
+                self._bufs[lay] = (None, dev.empty((N1, B, d, 3, 4), pad_bytes=vb.value - N1 * B * d * 96))  # + scratch tail
             else:
                 self._bufs[lay] = (dev.empty((N1, d, p, B)), dev.empty((N1, d, p, p, B)))
         self.layout = lay
