@@ -156,11 +156,13 @@ int rk_solve_sim(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, co
 /* Gather x[obs_ind[k], :, 0] and reduce the Gaussian observation log-likelihood + N(0, prior_sd^2) log-prior
  * per trajectory: the tail of the user log-posterior of docs/examples/parameter.md:188-210,331-354 (and of
  * src/rodeo/inference/basic.py:47-62 with a Gaussian obs_loglik).
- *   x_state (N+1, d, p, B); obs (n_obs, d) host-layout on device; obs_ind (n_obs) int32 on device;
+ *   state: the solver output holding the path -- layout RK_LAYOUT_BATCH_MINOR: x_state / mean_state (N+1, d, p, B);
+ *          layout RK_LAYOUT_TILE3: the tile buffer (N+1, B, d, 3, 4) (the mean is column 3);
+ *   obs (n_obs, d) row-major on device; obs_ind (n_obs) int32 on device (clamped to [0, N]);
  *   upars (n_prior, B) batch-minor or NULL (no prior term); out logpost (B).                              */
 int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n_block, int32_t n_bstate,
-                         const double* x_state, const double* obs, const int32_t* obs_ind, int32_t n_obs,
-                         double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
+                         int32_t layout, const double* state, const double* obs, const int32_t* obs_ind,
+                         int32_t n_obs, double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
                          double* logpost);
 
 /* ---- per-step operator boundary -------------------------------------------------------------------------

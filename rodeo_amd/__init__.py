@@ -10,6 +10,7 @@ from . import prior
 from . import kalmantv
 from . import ode
 from . import utils
+from . import inference
 from .solve import solve_sim, solve_mv, SolvePlan
 from .prior.ibm import ibm_init
 from .prior.indep_init import indep_init

@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(64) interrogate_kernel(SolveArgs a, double t, 
 }
 
 // ---- Gaussian observation log-posterior reduction (docs/examples/parameter.md:188-210) ---------------------------
-__global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, const double* x, const double* obs, const int32_t* obs_ind,
+__global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile, const double* x, const double* obs, const int32_t* obs_ind,
                                      int n_obs, double noise_sd, const double* upars, int n_prior, double prior_sd,
                                      double* out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,7 +311,8 @@ __global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, const dou
         ni = ni < 0 ? 0 : (ni > n_steps ? n_steps : ni);     // never index outside the (N+1)-long path
         const size_t n = (size_t)ni;
         for (int blk = 0; blk < D; ++blk) {
-            const double xv = x[((n * D + blk) * P + 0) * (size_t)B + b];
+            const double xv = tile ? x[((n * B + b) * D + blk) * 12 + 3]          // row 0 of [Sigma | mu]
+                                   : x[((n * D + blk) * P + 0) * (size_t)B + b];
             const double zz = (obs[(size_t)k * D + blk] - xv) / noise_sd;
             acc += -0.5 * zz * zz - lsd - LOG_SQRT_2PI;       // scipy.stats.norm.logpdf
         }
@@ -550,15 +551,18 @@ int rk_interrogate_batched(rk_handle h, const rk_solve_cfg* c, const rk_solve_in
 }
 
 int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n_block, int32_t n_bstate,
-                         const double* x_state, const double* obs, const int32_t* obs_ind, int32_t n_obs,
-                         double noise_sd, const double* upars, int32_t n_prior, double prior_sd, double* logpost) {
+                         int32_t layout, const double* x_state, const double* obs, const int32_t* obs_ind,
+                         int32_t n_obs, double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
+                         double* logpost) {
     RK_REQUIRE(h && x_state && obs && obs_ind && logpost, RK_ERR_INVALID, "rk_gauss_obs_logpost: null argument");
+    RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR || (layout == RK_LAYOUT_TILE3 && n_bstate == 3), RK_ERR_INVALID,
+               "rk_gauss_obs_logpost: bad layout %d for n_bstate %d", layout, n_bstate);
     RK_REQUIRE(n_traj >= 1 && n_obs >= 0 && n_block >= 1 && n_bstate >= 1 && n_steps >= 1, RK_ERR_INVALID,
                "rk_gauss_obs_logpost: bad dimension");
     RK_HIP(hipSetDevice(h->device));
     LaunchTimer t(h, "gauss_logpost_kernel");
     hipLaunchKernelGGL(gauss_logpost_kernel, dim3(div_up(n_traj, 64)), dim3(64), 0, h->stream, n_traj, n_steps, n_block,
-                       n_bstate, x_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
+                       n_bstate, layout == RK_LAYOUT_TILE3 ? 1 : 0, x_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

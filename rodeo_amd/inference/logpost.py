@@ -1,0 +1,53 @@
+"""
+Gaussian observation log-likelihood (+ optional normal log-prior) per trajectory, reduced on the device from a solver
+output that is still resident in HBM -- the tail of rodeo's user-level log-posteriors:
+
+    obs_ind  = searchsorted(sim_times, obs_times)                          docs/examples/parameter.md:149
+    loglik   = sum norm.logpdf(obs, loc = Xt[obs_ind, :, 0], scale = noise_sd)    parameter.md:197-210
+    logprior = sum norm.logpdf(upars[:n_prior], 0, prior_sd)               parameter.md:188-194
+
+Only B doubles leave the GPU instead of the (B, N+1, d, p) path.
+"""
+import ctypes as C
+import numpy as np
+from .. import _lib
+
+
+def obs_index(t_min, t_max, n_steps, obs_times):
+    """Indices of the solver grid closest-from-the-right to the observation times (``jnp.searchsorted``)."""
+    sim_times = np.linspace(t_min, t_max, n_steps + 1)
+    return np.searchsorted(sim_times, np.asarray(obs_times, dtype=np.float64)).astype(np.int32)
+
+
+def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10.0, n_prior=None, which="auto"):
+    """
+    ``plan``: a ``SolvePlan`` whose ``mv()`` / ``sim()`` has been launched.  ``obs_data`` (n_obs, d), ``obs_ind``
+    (n_obs,) int; ``upars`` (B, k) optional unconstrained parameters whose first ``n_prior`` entries get a
+    N(0, prior_sd^2) prior.  Returns a DeviceArray of shape (B,) (call ``.to_host()``).
+    """
+    dev = plan.dev
+    obs = np.ascontiguousarray(obs_data, dtype=np.float64)
+    ind = np.ascontiguousarray(obs_ind, dtype=np.int32)
+    if obs.shape != (ind.shape[0], plan.d):
+        raise ValueError(f"obs_data must have shape (n_obs, {plan.d})")
+    if ind.size and (ind.min() < 0 or ind.max() > plan.N):
+        raise ValueError("obs_ind outside the solver grid")
+    if which == "auto":
+        which = "x" if plan.x_state is not None and plan.last_mode == _lib.MODE_SIM else "mean"
+    if which == "x":
+        state, layout = plan.x_state, _lib.LAYOUT_BATCH_MINOR
+    else:
+        layout = plan.layout
+        state = plan.var_state if layout == _lib.LAYOUT_TILE3 else plan.mean_state
+    d_obs, d_ind = dev.to_device(obs), dev.to_device(ind)
+    d_up, k = None, 0
+    if upars is not None:
+        up = np.asarray(upars, dtype=np.float64)
+        k = up.shape[1] if n_prior is None else int(n_prior)
+        d_up = dev.to_device(np.ascontiguousarray(up[:, :k].T))
+    out = dev.empty((plan.B,))
+    _lib.check(dev.lib.rk_gauss_obs_logpost(dev.h, plan.B, plan.N, plan.d, plan.p, layout, state.ptr, d_obs.ptr,
+                                            d_ind.ptr, ind.shape[0], float(noise_sd),
+                                            d_up.ptr if d_up is not None else None, k, float(prior_sd), out.ptr))
+    out._keep = (d_obs, d_ind, d_up)          # keep inputs alive until the stream has run the kernel
+    return out

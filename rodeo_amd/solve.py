@@ -119,6 +119,7 @@ class SolvePlan:
             theta=self._theta.ptr if self._theta is not None else None, theta_batched=int(Bt is not None))
         self._store_pred = store_pred
         self.layout = None                 # layout of the last launch (RK_LAYOUT_*)
+        self.last_mode = None              # RK_MODE_* of the last launch
         self._bufs = {}                    # layout -> (mean_state, var_state)
         self.mean_state = self.var_state = self.mean_pred = self.var_pred = self.x_state = None
         self._out = _lib.SolveOut()
@@ -151,6 +152,7 @@ class SolvePlan:
     # ---- launches (asynchronous) ----
     def _call(self, fn, key, mode):
         self._prepare_out(mode)
+        self.last_mode = mode
         self.cfg.seed = _seed(key)
         _lib.check(fn(self.dev.h, C.byref(self.cfg), C.byref(self.inp), C.byref(self._out)))
 

@@ -1,0 +1,97 @@
+"""
+GPU parity of the callers of the hot path: ``inference.basic`` (src/rodeo/inference/basic.py:47-62) and the
+pseudo-marginal log-posterior of docs/examples/parameter.md:331-354 (BASELINE config 4's per-draw quantity:
+constrain -> first_order_pad -> ibm_init(sigma per draw) -> solve_sim + interrogate_chkrebtii -> gather at the
+observation times -> Gaussian log-likelihood + N(0, 10^2) log-prior), against the same computation on the oracle.
+"""
+import functools
+import numpy as np
+import pytest
+from scipy.stats import norm
+from oracle import scan, odes, priors, interrogations as oi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rodeo_amd
+    return rodeo_amd
+
+
+def _setup(ra, n_steps=80, t_max=4.0, n_obs=5):
+    theta = np.array([0.2, 0.2, 3.0])
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    x0 = init(np.array([-1., 1.]), 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / n_steps, 3, np.array([.1, .1]))
+    obs_times = np.linspace(0, t_max, n_obs)
+    rng = np.random.default_rng(3)
+    m, _ = scan.solve_mv(None, odes.fitzhugh_nagumo, W, x0, 0., t_max, n_steps, oi.interrogate_kramer, prior, theta=theta)
+    ind = np.searchsorted(np.linspace(0, t_max, n_steps + 1), obs_times)
+    Y = m[ind, :, 0] + np.sqrt(0.005) * rng.standard_normal((n_obs, 2))
+    return dict(theta=theta, W=W, x0=x0, prior=prior, obs_times=obs_times, Y=Y, ind=ind, N=n_steps, t_max=t_max)
+
+
+def test_basic_gaussian_and_callable(ra):
+    from rodeo_amd.inference.basic import GaussianObsLoglik
+    s = _setup(ra)
+    sd = np.sqrt(0.005)
+    args = (None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0., s["t_max"], s["N"], ra.interrogate.interrogate_kramer,
+            s["prior"], s["Y"], s["obs_times"])
+    ll_dev = ra.inference.basic(*args, GaussianObsLoglik(sd), theta=s["theta"])
+    mo, _ = scan.solve_mv(None, odes.fitzhugh_nagumo, s["W"], s["x0"], 0., s["t_max"], s["N"], oi.interrogate_kramer,
+                          s["prior"], theta=s["theta"])
+    ll_ref = np.sum(norm.logpdf(s["Y"], loc=mo[s["ind"], :, 0], scale=sd))
+    assert isinstance(ll_dev, float) and abs(ll_dev - ll_ref) < 1e-7 * max(1.0, abs(ll_ref))
+    # an arbitrary Python obs_loglik with the reference's signature
+    def my_loglik(obs_data, ode_data, **params):
+        return np.sum(norm.logpdf(obs_data, loc=ode_data[:, :, 0], scale=sd))
+    ll_call = ra.inference.basic(*args, my_loglik, theta=s["theta"])
+    assert abs(ll_call - ll_ref) < 1e-7 * max(1.0, abs(ll_ref))
+    # batched (tile layout inside): B trajectories
+    B = 5
+    th = s["theta"] * np.exp(0.05 * np.random.default_rng(0).standard_normal((B, 3)))
+    _, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    x0 = init(np.tile([-1., 1.], (B, 1)), 0., theta=th)
+    llb = ra.inference.basic(None, ra.ode.fitzhugh_nagumo, s["W"], x0, 0., s["t_max"], s["N"],
+                             ra.interrogate.interrogate_kramer, s["prior"], s["Y"], s["obs_times"],
+                             GaussianObsLoglik(sd), theta=th)
+    mB, _ = scan.solve_mv(None, odes.fitzhugh_nagumo, s["W"], x0, 0., s["t_max"], s["N"], oi.interrogate_kramer,
+                          s["prior"], theta=th)
+    ref = np.array([np.sum(norm.logpdf(s["Y"], loc=mB[b][s["ind"], :, 0], scale=sd)) for b in range(B)])
+    np.testing.assert_allclose(llb, ref, rtol=1e-7, atol=1e-7)
+
+
+def test_chkrebtii_pseudo_marginal_logposterior(ra):
+    """docs/examples/parameter.md:227-236, 331-354 for a batch of parameter draws with per-draw sigma."""
+    from rodeo_amd.inference import gauss_obs_logpost, obs_index
+    s = _setup(ra, n_steps=100, t_max=5.0, n_obs=6)
+    B, N, t_max = 16, s["N"], s["t_max"]
+    rng = np.random.default_rng(20242)
+    u0 = np.concatenate([np.log(s["theta"]), [-1., 1.], [.1, .1]])
+    scale = np.array([0.01, 0.1, 0.01, 0.01, 0.01, 0.01, 0.01])
+    upars = u0 + scale * rng.standard_normal((B, 7))
+    theta, x0v, sigma = np.exp(upars[:, :3]), upars[:, 3:5], upars[:, 5:]
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    X0 = init(x0v, 0., theta=theta)
+    prior = ra.ibm_init(t_max / N, 3, sigma)                                   # batched prior_var (B, 2, 3, 3)
+    g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="standard")
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, X0, 0., t_max, N, g, prior, theta=theta)
+    plan.sim(99)
+    ind = obs_index(0., t_max, N, s["obs_times"])
+    np.testing.assert_array_equal(ind, s["ind"])
+    sd = np.sqrt(0.005)
+    lp = gauss_obs_logpost(plan, s["Y"], ind, sd, upars=upars, prior_sd=10.0, n_prior=5).to_host()
+    o = functools.partial(oi.interrogate_chkrebtii, kalman_type="standard")
+    xo = scan.solve_sim(99, odes.fitzhugh_nagumo, W, X0, 0., t_max, N, o, priors.ibm_init(t_max / N, 3, sigma[0])
+                        if False else prior, theta=theta)
+    ref = np.array([np.sum(norm.logpdf(s["Y"], loc=xo[b][ind, :, 0], scale=sd)) +
+                    np.sum(norm.logpdf(upars[b, :5], 0., 10.)) for b in range(B)])
+    np.testing.assert_allclose(lp, ref, rtol=1e-6, atol=1e-5)
+    # the same reduction from the downloaded path
+    x = plan.x_host()
+    ref2 = np.array([np.sum(norm.logpdf(s["Y"], loc=x[b][ind, :, 0], scale=sd)) +
+                     np.sum(norm.logpdf(upars[b, :5], 0., 10.)) for b in range(B)])
+    np.testing.assert_allclose(lp, ref2, rtol=1e-12, atol=1e-9)
+    with pytest.raises(ValueError):
+        gauss_obs_logpost(plan, s["Y"], ind + 1000, sd)
