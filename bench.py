@@ -94,8 +94,12 @@ def main():
     import rodeo_amd as ra                      # loads librodeo_kalman.so BEFORE torch's bundled ROCm libraries
     from rodeo_amd import _lib
     import ctypes as C
-    dev = ra.Device(local_rank)
-    lib = dev.lib
+    lib = _lib.load()
+    n_dev = C.c_int(0)
+    _lib.check(lib.rk_device_count(C.byref(n_dev)))
+    if local_rank >= n_dev.value:       # rehearsal on a box with fewer GPUs than ranks: share devices (RCCL then falls back)
+        print(f"[rank {rank}] only {n_dev.value} GPU(s) visible; sharing device {local_rank % n_dev.value}", file=sys.stderr)
+    dev = ra.Device(local_rank % max(n_dev.value, 1))
 
     dist = None
     comm = "none"
@@ -103,6 +107,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
         comm = "gloo"
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)                     # RCCL prints diagnostics on stdout; keep stdout for the one JSON line
         try:
             uid = (C.c_char * _lib.COMM_UID_BYTES)()
             if rank == 0:
@@ -114,6 +120,10 @@ def main():
             comm = "rccl"
         except Exception as e:
             print(f"[rank {rank}] RCCL communicator unavailable ({e}); using gloo for barriers", file=sys.stderr)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     def barrier():
         dev.sync()

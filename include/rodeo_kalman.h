@@ -142,7 +142,7 @@ typedef struct {
  * RK_LAYOUT_BATCH_MINOR.  The caller sizes and interprets out->mean_state / var_state accordingly.             */
 int rk_solve_layout(const rk_solve_cfg* cfg, int32_t mode, int32_t* layout);
 /* bytes of the output arrays for a configuration in the given layout (any pointer may be NULL);
- * RK_LAYOUT_TILE3: *mean_bytes = 0, *var_bytes = ((N+1) * B * d * 12 + 64 * ceil(B * d / 4)) * 8 -- the buffer MUST
+ * RK_LAYOUT_TILE3: *mean_bytes = 0, *var_bytes = ((N+1) * B * d * 12 + 128 * ceil(B * d / 8)) * 8 -- the buffer MUST
  * have this size: behind the tiles sits a scratch tail (64 doubles per wave) that lanes without an output slot use. */
 int rk_solve_sizes(const rk_solve_cfg* cfg, int32_t layout, size_t* mean_bytes, size_t* var_bytes);
 

@@ -481,7 +481,7 @@ int rk_solve_sizes(const rk_solve_cfg* c, int32_t layout, size_t* mean_bytes, si
         if (mean_bytes) *mean_bytes = 0;
         if (var_bytes) {
             const size_t n_tiles = (size_t)c->n_block * (size_t)c->n_traj;
-            *var_bytes = ((size_t)(c->n_steps + 1) * n_tiles * 12 + ((n_tiles + 3) / 4) * 64) * sizeof(double);
+            *var_bytes = ((size_t)(c->n_steps + 1) * n_tiles * 12 + ((n_tiles + 7) / 8) * 128) * sizeof(double);
         }
         return RK_OK;
     }

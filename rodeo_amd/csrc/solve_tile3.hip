@@ -149,29 +149,39 @@ __device__ __forceinline__ int lds_byte(int s, int g, int which, int idx) {
     return item * ITEM_BYTES + which * 128 + ((idx ^ (item & 15)) << 3);
 }
 
-__global__ void __launch_bounds__(192) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D, int dbg) {
+// Workgroup = 8 waves for 8 tiles (two groups of 4).  A workgroup's waves go to the CU's four SIMDs cyclically, so
+// waves w and w + 4 share a SIMD: the two consumers (waves 0, 1) get a SIMD each to themselves (waves 4, 5 exit at
+// once), and the four producer waves (2, 3, 6, 7) share the other two SIMDs.  This is a speed assumption only --
+// any placement gives the same results.
+__global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D, int dbg) {
     constexpr int P = 3;
-    __shared__ __attribute__((aligned(16))) char lds_raw[2 * BUF_BYTES];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) char lds_all[2 * 2 * BUF_BYTES];
+    const int wave_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * TILE_DOUBLES;
     const int n_chunks = (a.N - 1 + CHUNK - 1) / CHUNK;            // steps n = N-1 .. 1
-    // this workgroup's 64-double slice of the scratch tail (row 3 of its tiles: e_3)
-    double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)blockIdx.x * 64;
 
     // constant entries of the hand-off tiles (row 3 = e_3; column 3 of G~^T = e_3) are written once
-    for (int i = threadIdx.x; i < 2 * 64 * 3 * 16; i += 192) {
+    for (int i = threadIdx.x; i < 2 * 2 * 64 * 3 * 16; i += 512) {
         const int idx = i & 15, which = (i >> 4) % 3, item = ((i >> 4) / 3) & 63, buf = i / (64 * 3 * 16);
         const double v = (idx == 15) ? 1.0 : 0.0;
-        *(double*)(lds_raw + buf * BUF_BYTES + lds_byte(item >> 2, item & 3, which, idx)) = v;
+        *(double*)(lds_all + buf * BUF_BYTES + lds_byte(item >> 2, item & 3, which, idx)) = v;
     }
     __syncthreads();
+    if (wave_id == 4 || wave_id == 5) return;                      // placeholders that keep the consumers' SIMDs free
+
+    const int grp = wave_id & 1;                                   // which group of 4 tiles
+    const int wave = wave_id < 2 ? 0 : (wave_id < 4 ? 1 : 2);       // 0 consumer, 1 / 2 producers of parity 0 / 1
+    const int tw = blockIdx.x * 2 + grp;                           // tile-wave index: tiles 4 tw .. 4 tw + 3
+    char* const lds_raw = lds_all + grp * 2 * BUF_BYTES;
+    // this tile-wave's 64-double slice of the scratch tail (row 3 of its tiles: e_3)
+    double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)tw * 64;
 
     if (wave >= 1) {
         // ---------------- producers: one lane per (step-in-chunk, tile) ----------------
         const int p = wave - 1;
         const int s = lane >> 2, g = lane & 3;
-        int tau = blockIdx.x * 4 + g;
+        int tau = tw * 4 + g;
         if (tau >= n_tiles) tau = n_tiles - 1;
         const int b = tau / D, blk = tau - b * D;
         double Q[P][P], R[P][P];
@@ -244,7 +254,7 @@ __global__ void __launch_bounds__(192) bwd_mv_tile3_kernel(SolveArgs a, double* 
         }
     } else {
         // ---------------- consumer: the carry recursion on MFMA tiles ----------------
-        const TileCoord tc = tile_coord<1>(blockIdx.x, lane, n_tiles);      // (b, blk) not needed here
+        const TileCoord tc = tile_coord<1>(tw, lane, n_tiles);              // (b, blk) not needed here
         const int r = tc.r, g = tc.g, c = tc.c, idx = r * 4 + c;
         const bool st = tc.valid && r < 3;
         // lanes without a slot (row 3, tiles past the end) read and write the scratch tail with stride 0: row 3 of
@@ -296,7 +306,7 @@ __global__ void __launch_bounds__(192) bwd_mv_tile3_kernel(SolveArgs a, double* 
             }
             __syncthreads();
         }
-        if ((dbg & 4) && blockIdx.x == 0 && lane == 3)      // shader cycles of the whole consumer loop -> scratch tail
+        if ((dbg & 4) && tw == 0 && lane == 3)      // shader cycles of the whole consumer loop -> scratch tail
             dump[lane] = (double)(__builtin_amdgcn_s_memtime() - stamp0);
     }
 }
@@ -340,7 +350,7 @@ int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     else rc = launch_fwd_tile<HigherOrder>(h, c, a, tiles);
     if (rc || mode == 0 || a.N < 2) return rc;
     LaunchTimer t(h, "bwd_mv_tile3_kernel");
-    hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(192), 0, h->stream, a, tiles, a.D, (c->flags >> 16) & 7);
+    hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 8)), dim3(512), 0, h->stream, a, tiles, a.D, (c->flags >> 16) & 7);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

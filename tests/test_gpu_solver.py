@@ -305,3 +305,19 @@ def test_tile_path_higher_order_single_block(ra):
     mo, vo = scan.solve_mv(None, odes.higher_order, W, x0, 0.0, 5.0, 100, oi.interrogate_kramer, prior)
     assert np.max(np.abs(m - mo)) < 1e-9
     _vclose(v, vo, 1e-9)
+
+
+def test_rccl_single_rank_comm(ra):
+    """RCCL path of the C ABI with one rank: communicator init, all-gather and barrier on the device stream."""
+    import ctypes as C
+    from rodeo_amd import _lib
+    from rodeo_amd.shard import RcclComm
+    dev = ra.Device(0)
+    comm = RcclComm(dev, 0, 1, bcast=lambda b, src=0: b)
+    send = dev.to_device(np.arange(8, dtype=np.float64))
+    recv = dev.zeros((8,))
+    comm.allgather(send, recv, 8)
+    comm.barrier()
+    np.testing.assert_array_equal(recv.to_host(), np.arange(8.0))
+    comm.close()
+    dev.close()
