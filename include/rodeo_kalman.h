@@ -74,6 +74,8 @@ extern "C" {
 #define RK_LAYOUT_BATCH_MINOR  0  /* mean_state (N+1, d, p, B), var_state (N+1, d, p, p, B)                  */
 #define RK_LAYOUT_TILE3        1  /* n_bstate = 3 only: var_state holds (N+1, B, d, 3, 4) doubles, row i of a
                                      block = [Sigma[i][0..2], mu[i]]; mean_state is not used (may be NULL)  */
+#define RK_LAYOUT_TRAJ_MAJOR   2  /* dense large-block path: the reference's own layout with a leading batch
+                                     axis, mean_state (B, N+1, d, p), var_state (B, N+1, d, p, p)            */
 
 typedef struct rk_handle_s* rk_handle;
 
@@ -135,6 +137,8 @@ typedef struct {
     double* var_pred;       /* (N+1, d, p, p, B)                                                            */
     /* rk_solve_sim: the sample path; mean_state / var_state are then the filter workspace                  */
     double* x_state;        /* (N+1, d, p, B)                                                               */
+    /* scratch for the dense large-block path: rk_solve_workspace_bytes() bytes (NULL if that returns 0)     */
+    void*   workspace;
 } rk_solve_out;
 
 /* Output layout the fused kernels use for this configuration and call (RK_MODE_*).  The MFMA-tile kernels
@@ -145,6 +149,9 @@ int rk_solve_layout(const rk_solve_cfg* cfg, int32_t mode, int32_t* layout);
  * RK_LAYOUT_TILE3: *mean_bytes = 0, *var_bytes = ((N+1) * B * d * 12 + 128 * ceil(B * d / 8)) * 8 -- the buffer MUST
  * have this size: behind the tiles sits a scratch tail (64 doubles per wave) that lanes without an output slot use. */
 int rk_solve_sizes(const rk_solve_cfg* cfg, int32_t layout, size_t* mean_bytes, size_t* var_bytes);
+
+/* bytes of device scratch (rk_solve_out.workspace) the configuration needs; 0 for the small-block kernels */
+int rk_solve_workspace_bytes(const rk_solve_cfg* cfg, int32_t mode, size_t* bytes);
 
 /* forward pass only: src/rodeo/solve.py:31-122 (_solve_filter).  out->mean_state/var_state <- filtered. */
 int rk_solve_filter(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out);

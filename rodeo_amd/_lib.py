@@ -18,7 +18,7 @@ RHS_FITZHUGH_NAGUMO, RHS_LORENZ63, RHS_HIGHER_ORDER, RHS_LINEAR_DENSE = 1, 2, 3,
 FLAG_STORE_PRED = 1
 FLAG_BATCH_MINOR = 2
 MODE_FILTER, MODE_MV, MODE_SIM = 0, 1, 2
-LAYOUT_BATCH_MINOR, LAYOUT_TILE3 = 0, 1
+LAYOUT_BATCH_MINOR, LAYOUT_TILE3, LAYOUT_TRAJ_MAJOR = 0, 1, 2
 COMM_UID_BYTES = 128
 
 
@@ -45,7 +45,7 @@ class SolveIn(C.Structure):
 
 class SolveOut(C.Structure):
     _fields_ = [("mean_state", C.c_void_p), ("var_state", C.c_void_p), ("mean_pred", C.c_void_p),
-                ("var_pred", C.c_void_p), ("x_state", C.c_void_p)]
+                ("var_pred", C.c_void_p), ("x_state", C.c_void_p), ("workspace", C.c_void_p)]
 
 
 class OpCfg(C.Structure):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "rk_profile_last": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_D), C.POINTER(C.c_int)]),
     "rk_solve_layout": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(_I)]),
     "rk_solve_sizes": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "rk_solve_workspace_bytes": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(C.c_size_t)]),
     "rk_solve_filter": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut)]),
     "rk_solve_mv": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut)]),
     "rk_solve_sim": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut)]),

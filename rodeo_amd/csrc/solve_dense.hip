@@ -1,0 +1,327 @@
+// Dense large-block solver (BASELINE config 5: the "non-block" form of src/rodeo/prior/indep_init.py:8-23 -- one
+// dense block of n_vars * n_deriv states with n_bmeas = n_vars measurements; examples/solve_nb.py:55-260 is the
+// reference's own statement of this path).  One 256-thread workgroup per trajectory runs the whole time loop of
+//   src/rodeo/solve.py:31-122 (forward)  and  src/rodeo/solve.py:257-301 (backward mean/variance smoother)
+// with every p x p operand in global memory (the per-trajectory working set, ~1 MB at p = 160, stays in L2 / the
+// Infinity Cache) and register-tiled fp64 GEMMs; all LU solves use partial pivoting like src/rodeo/utils.py:119.
+//
+// Layout: trajectory-major = the reference's own layout with a leading batch axis:
+//   mean (B, N+1, p), var (B, N+1, p, p)  (n_block = 1), so a workgroup streams contiguous p x p matrices.
+//
+// First version: correct and roofline-aware but not tuned -- the GEMMs are VALU register-tiled (4 x 4 per thread),
+// the LU is unblocked.  (On MI355X the fp64 MFMA peak equals the fp64 VALU peak; MFMA's gain here is 4x fewer
+// operand loads, which is the next step for this path.)
+#include "common.hpp"
+#include "linalg_small.hpp"
+#include "solve_args.hpp"
+
+namespace rk {
+
+struct DenseArgs {
+    int B, N, p, m, itg;
+    double t_min, t_max;
+    const double *W, *x0, *Q, *R, *theta;      // W (m,p), Q,R (p,p) shared; x0 (p[,B]); theta = A (m,m[,B])
+    int x0_b, theta_b;
+    double *mean, *var;                        // (B, N+1, p), (B, N+1, p, p)
+    double* ws;                                // workspace, ws_stride doubles per trajectory
+    size_t ws_stride;
+};
+
+constexpr int DT = 256;
+
+// C (M x N, ldc) = ce * E + cab * op(A) op(B); op = transpose if TA / TB.  Row-major, global memory, the whole
+// workgroup cooperates: thread (ty, tx) of a 16 x 16 grid owns the 4 x 4 micro-tile {ty + 16 a} x {tx + 16 b} of each
+// 64 x 64 block of C.  E may alias C (each element is read and written by the same thread).
+template <bool TA, bool TB>
+__device__ void wg_gemm(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
+                        const double* E, int lde, double ce, double cab) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    for (int bi = 0; bi < M; bi += 64)
+        for (int bj = 0; bj < N; bj += 64) {
+            int ia[4], jb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ia[q] = min(bi + ty + 16 * q, M - 1);
+                jb[q] = min(bj + tx + 16 * q, N - 1);
+            }
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+            for (int k = 0; k < K; ++k) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    av[q] = TA ? A[(size_t)k * lda + ia[q]] : A[(size_t)ia[q] * lda + k];
+                    bv[q] = TB ? B[(size_t)jb[q] * ldb + k] : B[(size_t)k * ldb + jb[q]];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = bi + ty + 16 * a, j = bj + tx + 16 * b;
+                    if (i < M && j < N) {
+                        double v = cab * acc[a][b];
+                        if (E) v = fma(ce, E[(size_t)i * lde + j], v);
+                        C[(size_t)i * ldc + j] = v;
+                    }
+                }
+        }
+    __syncthreads();
+}
+
+// y (M) = ce * e + cab * op(A) x ; A (M x K) or, if TA, A is (K x M) and op(A) = A^T
+template <bool TA>
+__device__ void wg_gemv(double* y, const double* A, int lda, const double* x, int M, int K, const double* e,
+                        double ce, double cab) {
+    for (int i = threadIdx.x; i < M; i += DT) {
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s = fma(TA ? A[(size_t)k * lda + i] : A[(size_t)i * lda + k], x[k], s);
+        s *= cab;
+        if (e) s = fma(ce, e[i], s);
+        y[i] = s;
+    }
+    __syncthreads();
+}
+
+// In-place LU with partial pivoting of A (n x n, lda) -- first maximum of |a_ik| like LAPACK getrf -- then
+// X = A^{-1} Bm for the nr right-hand-side columns of Bm (n x nr, ldb), overwritten.  piv: n ints in global memory.
+__device__ void wg_lu_solve(double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
+    __shared__ double red_v[DT];
+    __shared__ int red_i[DT];
+    for (int k = 0; k < n; ++k) {
+        // pivot search
+        double best = -1.0;
+        int bi = k;
+        for (int i = k + threadIdx.x; i < n; i += DT) {
+            const double v = fabs(A[(size_t)i * lda + k]);
+            if (v > best) { best = v; bi = i; }             // ascending i per thread: first maximum
+        }
+        red_v[threadIdx.x] = best;
+        red_i[threadIdx.x] = bi;
+        __syncthreads();
+        for (int s = DT / 2; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+                const double v2 = red_v[threadIdx.x + s];
+                const int i2 = red_i[threadIdx.x + s];
+                if (v2 > red_v[threadIdx.x] || (v2 == red_v[threadIdx.x] && i2 < red_i[threadIdx.x])) {
+                    red_v[threadIdx.x] = v2;
+                    red_i[threadIdx.x] = i2;
+                }
+            }
+            __syncthreads();
+        }
+        const int pk = red_i[0];
+        if (threadIdx.x == 0) piv[k] = pk;
+        if (pk != k)
+            for (int j = threadIdx.x; j < n; j += DT) {
+                const double t = A[(size_t)k * lda + j];
+                A[(size_t)k * lda + j] = A[(size_t)pk * lda + j];
+                A[(size_t)pk * lda + j] = t;
+            }
+        __syncthreads();
+        const double r = 1.0 / A[(size_t)k * lda + k];
+        for (int i = k + 1 + threadIdx.x; i < n; i += DT) A[(size_t)i * lda + k] *= r;
+        __syncthreads();
+        // trailing update: rows k+1.., columns k+1..
+        const int rem = n - k - 1;
+        for (int e = threadIdx.x; e < rem * rem; e += DT) {
+            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+            A[(size_t)i * lda + j] = fma(-A[(size_t)i * lda + k], A[(size_t)k * lda + j], A[(size_t)i * lda + j]);
+        }
+        __syncthreads();
+    }
+    // each thread solves whole right-hand-side columns: row swaps, forward (unit lower), backward (upper)
+    for (int c = threadIdx.x; c < nr; c += DT) {
+        for (int k = 0; k < n; ++k) {                       // P b: all row interchanges first (LAPACK laswp)
+            const int pk = piv[k];
+            if (pk != k) {
+                const double t = Bm[(size_t)k * ldb + c];
+                Bm[(size_t)k * ldb + c] = Bm[(size_t)pk * ldb + c];
+                Bm[(size_t)pk * ldb + c] = t;
+            }
+        }
+        for (int k = 0; k < n; ++k) {
+            const double bk = Bm[(size_t)k * ldb + c];
+            for (int i = k + 1; i < n; ++i)
+                Bm[(size_t)i * ldb + c] = fma(-A[(size_t)i * lda + k], bk, Bm[(size_t)i * ldb + c]);
+        }
+        for (int k = n - 1; k >= 0; --k) {
+            double s = Bm[(size_t)k * ldb + c];
+            for (int i = k + 1; i < n; ++i) s = fma(-A[(size_t)k * lda + i], Bm[(size_t)i * ldb + c], s);
+            Bm[(size_t)k * ldb + c] = s / A[(size_t)k * lda + k];
+        }
+    }
+    __syncthreads();
+}
+
+struct DenseWs {
+    double *A1, *A2, *A3, *A4, *Wt, *WS, *X, *S, *mup, *f, *yhat, *dm;
+    int* piv;
+};
+
+__device__ DenseWs carve(double* w, int p, int m) {
+    DenseWs d;
+    const size_t pp = (size_t)p * p, mp = (size_t)m * p;
+    d.A1 = w; d.A2 = d.A1 + pp; d.A3 = d.A2 + pp; d.A4 = d.A3 + pp;
+    d.Wt = d.A4 + pp; d.WS = d.Wt + mp; d.X = d.WS + mp; d.S = d.X + mp;
+    d.mup = d.S + (size_t)m * m; d.f = d.mup + p; d.yhat = d.f + m; d.dm = d.yhat + m;
+    d.piv = (int*)(d.dm + p);
+    return d;
+}
+
+size_t dense_ws_doubles(int p, int m) {
+    return 4 * (size_t)p * p + 3 * (size_t)m * p + (size_t)m * m + 2 * (size_t)p + 2 * (size_t)m + (size_t)(p + 1) / 2 + 8;
+}
+
+// predicted moments from (mu, Sigma): A1 = Q Sigma, A2 = A1 Q^T + R, mup = Q mu      (standard.py:57-59)
+__device__ void dense_predict(const DenseArgs& a, const DenseWs& w, const double* mu, const double* Sig) {
+    const int p = a.p;
+    wg_gemm<false, false>(w.A1, p, a.Q, p, Sig, p, p, p, p, nullptr, 0, 0.0, 1.0);
+    wg_gemm<false, true>(w.A2, p, w.A1, p, a.Q, p, p, p, p, a.R, p, 1.0, 1.0);
+    wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
+}
+
+__global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
+    const int b = blockIdx.x, p = a.p, m = a.m;
+    const int nd = p / m;                              // derivatives per variable: x_v = X[v * nd]
+    const DenseWs w = carve(a.ws + (size_t)b * a.ws_stride, p, m);
+    double* mean = a.mean + (size_t)b * (a.N + 1) * p;
+    double* var = a.var + (size_t)b * (a.N + 1) * p * p;
+    const double* Aode = a.theta;
+    // time 0: (ode_init, 0)   (solve.py:53-54, 114-121)
+    for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
+    for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
+    __syncthreads();
+    for (int n = 0; n < a.N; ++n) {
+        const double* mu = mean + (size_t)n * p;
+        const double* Sig = var + (size_t)n * p * p;
+        double* mu_o = mean + (size_t)(n + 1) * p;
+        double* Sig_o = var + (size_t)(n + 1) * p * p;
+        dense_predict(a, w, mu, Sig);
+        // ---- interrogation (interrogate.py) for the linear ODE f = A x, x_v = X[v * nd] ----
+        for (int i = threadIdx.x; i < m; i += DT) {
+            double s = 0.0;
+            for (int v = 0; v < m; ++v) {
+                const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+                s = fma(Aiv, w.mup[(size_t)v * nd], s);
+            }
+            w.f[i] = s;
+        }
+        for (int e = threadIdx.x; e < m * p; e += DT) {
+            const int i = e / p, j = e % p;
+            double Jij = 0.0;
+            if (a.itg == RK_INTERROGATE_KRAMER && j % nd == 0) {
+                const int v = j / nd;
+                Jij = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+            }
+            w.Wt[e] = a.W[e] + (-Jij);                                   // W + wgt_meas   (solve.py:79)
+        }
+        __syncthreads();
+        // yhat = W~ mu- + a ;  a = -f (+ J mu- for kramer, interrogate.py:81-82) ; J mu- = (W - W~) mu-
+        for (int i = threadIdx.x; i < m; i += DT) {
+            double jm = 0.0, wm = 0.0;
+            for (int j = 0; j < p; ++j) {
+                jm = fma(a.W[(size_t)i * p + j] - w.Wt[(size_t)i * p + j], w.mup[j], jm);
+                wm = fma(w.Wt[(size_t)i * p + j], w.mup[j], wm);
+            }
+            const double am = a.itg == RK_INTERROGATE_KRAMER ? -w.f[i] + jm : -w.f[i];
+            w.yhat[i] = wm + am;                                         // standard.py:93
+        }
+        // ---- update (standard.py:93-102) ----
+        wg_gemm<false, false>(w.WS, p, w.Wt, p, w.A2, p, m, p, p, nullptr, 0, 0.0, 1.0);          // W~ Sigma-
+        wg_gemm<false, true>(w.S, m, w.WS, p, w.Wt, p, m, m, p, nullptr, 0, 0.0, 1.0);            // (W~ Sigma-) W~^T
+        if (a.itg == RK_INTERROGATE_RODEO) {                              // + var_meas = W Sigma- W^T (W~ = W)
+            for (int e = threadIdx.x; e < m * m; e += DT) w.S[e] = w.S[e] + w.S[e];
+            __syncthreads();
+        }
+        wg_gemm<false, true>(w.X, p, w.Wt, p, w.A2, p, m, p, p, nullptr, 0, 0.0, 1.0);            // (Sigma- W~^T)^T
+        wg_lu_solve(w.S, m, w.X, p, m, p, w.piv);                                                  // X = K^T (utils.py:119)
+        for (int i = threadIdx.x; i < p; i += DT) {
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s = fma(w.X[(size_t)j * p + i], 0.0 - w.yhat[j], s);
+            mu_o[i] = w.mup[i] + s;                                      // standard.py:99-100 with x_meas = 0
+        }
+        wg_gemm<true, false>(Sig_o, p, w.X, p, w.WS, p, p, p, m, w.A2, p, 1.0, -1.0);             // Sigma- - K (W~ Sigma-)
+    }
+}
+
+__global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
+    const int b = blockIdx.x, p = a.p, m = a.m;
+    const DenseWs w = carve(a.ws + (size_t)b * a.ws_stride, p, m);
+    double* mean = a.mean + (size_t)b * (a.N + 1) * p;
+    double* var = a.var + (size_t)b * (a.N + 1) * p * p;
+    for (int n = a.N - 1; n >= 1; --n) {
+        double* mu_f = mean + (size_t)n * p;
+        double* Sig_f = var + (size_t)n * p * p;
+        const double* mu_s = mean + (size_t)(n + 1) * p;           // already smoothed (in place)
+        const double* Sig_s = var + (size_t)(n + 1) * p * p;
+        dense_predict(a, w, mu_f, Sig_f);                          // pred[n+1] re-evaluated from filt[n]
+        wg_gemm<false, true>(w.A3, p, a.Q, p, Sig_f, p, p, p, p, nullptr, 0, 0.0, 1.0);   // T^T = Q Sigma_f^T (standard.py:175)
+        for (int e = threadIdx.x; e < p * p; e += DT) w.A4[e] = Sig_s[e] - w.A2[e];        // Sigma_next - Sigma-
+        for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = mu_s[i] - w.mup[i];
+        __syncthreads();
+        wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv);                // A3 <- G^T = solve(Sigma-, T^T)   (standard.py:176)
+        for (int i = threadIdx.x; i < p; i += DT) {
+            double s = 0.0;
+            for (int j = 0; j < p; ++j) s = fma(w.A3[(size_t)j * p + i], w.dm[j], s);
+            w.mup[i] = mu_f[i] + s;                                // standard.py:213-214 (written after the barrier)
+        }
+        wg_gemm<true, false>(w.A1, p, w.A3, p, w.A4, p, p, p, p, nullptr, 0, 0.0, 1.0);    // G D
+        for (int i = threadIdx.x; i < p; i += DT) mu_f[i] = w.mup[i];
+        wg_gemm<false, false>(Sig_f, p, w.A1, p, w.A3, p, p, p, p, Sig_f, p, 1.0, 1.0);    // Sigma_f + (G D) G^T (standard.py:215-216)
+    }
+}
+
+bool dense_supported(const rk_solve_cfg* c, int mode) {
+    return c->rhs_id == RK_RHS_LINEAR_DENSE;
+}
+
+int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
+    RK_REQUIRE(c->n_block == 1, RK_ERR_UNSUPPORTED, "dense path: n_block must be 1 (use prior.indep_init), got %d", c->n_block);
+    RK_REQUIRE(c->n_bmeas >= 1 && c->n_bstate % c->n_bmeas == 0 && c->n_bstate / c->n_bmeas >= 2, RK_ERR_INVALID,
+               "dense linear ODE: n_bstate (%d) must be n_vars * n_deriv with n_vars = n_bmeas (%d), n_deriv >= 2",
+               c->n_bstate, c->n_bmeas);
+    RK_REQUIRE(mode != RK_MODE_SIM, RK_ERR_UNSUPPORTED, "dense path: solve_sim is not available yet");
+    RK_REQUIRE(c->interrogate != RK_INTERROGATE_CHKREBTII, RK_ERR_UNSUPPORTED,
+               "dense path: interrogate_chkrebtii is not available yet");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "dense path: kalman_type must be standard");
+    RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED), RK_ERR_UNSUPPORTED, "dense path: RK_FLAG_STORE_PRED is not available");
+    RK_REQUIRE(!in->ode_weight_batched && !in->prior_weight_batched && !in->prior_var_batched, RK_ERR_UNSUPPORTED,
+               "dense path: ode_weight and prior_pars must be shared by all trajectories");
+    RK_REQUIRE(in->theta && c->n_theta == c->n_bmeas * c->n_bmeas, RK_ERR_INVALID,
+               "dense linear ODE needs theta = A (n_vars x n_vars row-major), n_theta = %d", c->n_bmeas * c->n_bmeas);
+    return RK_OK;
+}
+
+int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, int mode) {
+    RK_REQUIRE(out->workspace, RK_ERR_INVALID, "dense path needs out->workspace (rk_solve_workspace_bytes)");
+    DenseArgs a;
+    a.B = c->n_traj; a.N = c->n_steps; a.p = c->n_bstate; a.m = c->n_bmeas; a.itg = c->interrogate;
+    a.t_min = c->t_min; a.t_max = c->t_max;
+    a.W = in->ode_weight; a.x0 = in->ode_init; a.Q = in->prior_weight; a.R = in->prior_var; a.theta = in->theta;
+    a.x0_b = in->ode_init_batched; a.theta_b = in->theta_batched;
+    a.mean = out->mean_state; a.var = out->var_state;
+    a.ws = (double*)out->workspace; a.ws_stride = dense_ws_doubles(a.p, a.m);
+    {
+        LaunchTimer t(h, "dense_fwd_kernel");
+        hipLaunchKernelGGL(dense_fwd_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+        t.stop();
+    }
+    RK_HIP(hipGetLastError());
+    if (mode == RK_MODE_MV && a.N >= 2) {
+        LaunchTimer t(h, "dense_bwd_mv_kernel");
+        hipLaunchKernelGGL(dense_bwd_mv_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+        t.stop();
+        RK_HIP(hipGetLastError());
+    }
+    return RK_OK;
+}
+
+}  // namespace rk

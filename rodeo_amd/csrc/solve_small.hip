@@ -456,6 +456,12 @@ static int launch_itg_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a
     return RK_OK;
 }
 
+// dense large-block path (solve_dense.hip)
+bool dense_supported(const rk_solve_cfg* c, int mode);
+int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode);
+int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, int mode);
+size_t dense_ws_doubles(int p, int m);
+
 // MFMA-tile path (solve_tile3.hip)
 bool tile3_supported(const rk_solve_cfg* c, int mode);
 int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
@@ -469,7 +475,14 @@ extern "C" {
 int rk_solve_layout(const rk_solve_cfg* c, int32_t mode, int32_t* layout) {
     RK_REQUIRE(c && layout, RK_ERR_INVALID, "rk_solve_layout: null argument");
     RK_REQUIRE(mode >= RK_MODE_FILTER && mode <= RK_MODE_SIM, RK_ERR_INVALID, "rk_solve_layout: bad mode %d", mode);
-    *layout = tile3_supported(c, mode) ? RK_LAYOUT_TILE3 : RK_LAYOUT_BATCH_MINOR;
+    *layout = dense_supported(c, mode) ? RK_LAYOUT_TRAJ_MAJOR
+              : (tile3_supported(c, mode) ? RK_LAYOUT_TILE3 : RK_LAYOUT_BATCH_MINOR);
+    return RK_OK;
+}
+
+int rk_solve_workspace_bytes(const rk_solve_cfg* c, int32_t mode, size_t* bytes) {
+    RK_REQUIRE(c && bytes, RK_ERR_INVALID, "rk_solve_workspace_bytes: null argument");
+    *bytes = dense_supported(c, mode) ? dense_ws_doubles(c->n_bstate, c->n_bmeas) * (size_t)c->n_traj * sizeof(double) : 0;
     return RK_OK;
 }
 
@@ -485,7 +498,7 @@ int rk_solve_sizes(const rk_solve_cfg* c, int32_t layout, size_t* mean_bytes, si
         }
         return RK_OK;
     }
-    RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR, RK_ERR_INVALID, "unknown layout %d", layout);
+    RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR || layout == RK_LAYOUT_TRAJ_MAJOR, RK_ERR_INVALID, "unknown layout %d", layout);
     if (mean_bytes) *mean_bytes = m;
     if (var_bytes) *var_bytes = m * c->n_bstate;
     return RK_OK;
@@ -496,9 +509,18 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     RK_REQUIRE(h, RK_ERR_INVALID, "null handle");
     int rc = check_cfg(c, in);
     if (rc) return rc;
-    const bool tile = tile3_supported(c, mode);
+    const bool dense = dense_supported(c, mode);
+    const bool tile = !dense && tile3_supported(c, mode);
     RK_REQUIRE(out && out->var_state && (tile || out->mean_state), RK_ERR_INVALID,
                "out->mean_state / var_state must not be NULL");
+    if (dense) {
+        rc = dense_check(c, in, mode);
+        if (rc) return rc;
+        RK_HIP(hipSetDevice(h->device));
+        h->prof.clear();
+        h->event_used = 0;
+        return dense_solve(h, c, in, out, mode);
+    }
     RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED) || (out->mean_pred && out->var_pred), RK_ERR_INVALID,
                "RK_FLAG_STORE_PRED needs out->mean_pred / var_pred");
     RK_REQUIRE(mode != 2 || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");

@@ -80,3 +80,34 @@ fitzhugh_nagumo = DeviceODE("fitzhugh_nagumo", _lib.RHS_FITZHUGH_NAGUMO, 2, 1, (
 lorenz63 = DeviceODE("lorenz63", _lib.RHS_LORENZ63, 3, 1, (("theta", 3),), _lorenz)
 #: x'' = sin(2t) - x (docs/examples/higher_order.md:47-59); no parameters
 higher_order = DeviceODE("higher_order", _lib.RHS_HIGHER_ORDER, 1, 1, (), _higher)
+
+
+def linear_dense(n_vars, n_deriv):
+    """
+    Linear ODE x' = A x in the dense single-block ("non-block") form produced by ``prior.indep_init``: the state is
+    X of shape (1, n_vars * n_deriv), variable-major (X[0, v * n_deriv + k] = k-th derivative of x_v), the output
+    has shape (1, n_vars).  The matrix is passed as the parameter ``A`` (n_vars, n_vars) [or (B, n_vars, n_vars)].
+    Mirrors how examples/solve_nb.py / examples/timings.py run rodeo without variable blocking.
+    """
+    idx0 = np.arange(n_vars) * n_deriv
+
+    def host(X, t, A):
+        A = np.asarray(A, dtype=np.float64)
+        if A.shape[-1] != n_vars:                          # packed (.., n_vars^2) form
+            A = A.reshape(A.shape[:-1] + (n_vars, n_vars))
+        x = X[..., 0, idx0]
+        return np.matmul(A, x[..., None])[..., 0][..., None, :]
+
+    ode = DeviceODE("linear_dense", _lib.RHS_LINEAR_DENSE, 1, n_vars, (("A", n_vars * n_vars),), host)
+    _pack = ode.pack_params
+
+    def pack(params):                                   # accept A as (n, n) or (B, n, n)
+        params = dict(params)
+        if "A" in params:
+            A = np.asarray(params["A"], dtype=np.float64)
+            params["A"] = A.reshape(A.shape[:-2] + (n_vars * n_vars,)) if A.ndim >= 2 and A.shape[-1] == n_vars and \
+                A.shape[-2] == n_vars else A
+        return _pack(params)
+
+    ode.pack_params = pack
+    return ode

@@ -121,6 +121,7 @@ class SolvePlan:
         self.layout = None                 # layout of the last launch (RK_LAYOUT_*)
         self.last_mode = None              # RK_MODE_* of the last launch
         self._bufs = {}                    # layout -> (mean_state, var_state)
+        self._ws = None                    # device scratch for the dense path
         self.mean_state = self.var_state = self.mean_pred = self.var_pred = self.x_state = None
         self._out = _lib.SolveOut()
 
@@ -135,6 +136,8 @@ class SolvePlan:
                 mb, vb = C.c_size_t(0), C.c_size_t(0)
                 _lib.check(dev.lib.rk_solve_sizes(C.byref(self.cfg), lay, C.byref(mb), C.byref(vb)))
                 self._bufs[lay] = (None, dev.empty((N1, B, d, 3, 4), pad_bytes=vb.value - N1 * B * d * 96))  # + scratch tail
+            elif lay == _lib.LAYOUT_TRAJ_MAJOR:
+                self._bufs[lay] = (dev.empty((B, N1, d, p)), dev.empty((B, N1, d, p, p)))
             else:
                 self._bufs[lay] = (dev.empty((N1, d, p, B)), dev.empty((N1, d, p, p, B)))
         self.layout = lay
@@ -143,7 +146,12 @@ class SolvePlan:
             self.mean_pred, self.var_pred = dev.empty((N1, d, p, B)), dev.empty((N1, d, p, p, B))
         if mode == _lib.MODE_SIM and self.x_state is None:
             self.x_state = dev.empty((N1, d, p, B))
+        wsb = C.c_size_t(0)
+        _lib.check(self.dev.lib.rk_solve_workspace_bytes(C.byref(self.cfg), mode, C.byref(wsb)))
+        if wsb.value and (self._ws is None or self._ws.nbytes < wsb.value):
+            self._ws = dev.empty((wsb.value // 8,))
         self._out = _lib.SolveOut(
+            workspace=self._ws.ptr if self._ws is not None else None,
             mean_state=self.mean_state.ptr if self.mean_state is not None else None, var_state=self.var_state.ptr,
             mean_pred=self.mean_pred.ptr if self.mean_pred is not None else None,
             var_pred=self.var_pred.ptr if self.var_pred is not None else None,
@@ -178,6 +186,9 @@ class SolvePlan:
         if self.layout == _lib.LAYOUT_TILE3:
             t = np.moveaxis(self.var_state.to_host(), 1, 0)         # (B, N+1, d, 3, 4): rows [Sigma | mu]
             mean, var = t[..., 3], t[..., :3]
+            return (mean, var) if self.batched else (mean[0], var[0])
+        if self.layout == _lib.LAYOUT_TRAJ_MAJOR:                    # already the reference layout
+            mean, var = self.mean_state.to_host(), self.var_state.to_host()
             return (mean, var) if self.batched else (mean[0], var[0])
         return self._host(self.mean_state), self._host(self.var_state)
 

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""
+Timings of the other BASELINE.json configurations (not the bench.py headline): C3 Lorenz63, C4 pseudo-marginal
+log-posterior (per GPU: 1024 draws), C5 dense 160-dim block.  Prints one JSON line per configuration.
+    python scripts/bench_configs.py [c3] [c4] [c5] [--c5-batch B] [--c5-steps N]
+"""
+import argparse, functools, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rodeo_amd as ra
+from rodeo_amd.inference import gauss_obs_logpost, obs_index
+
+
+def timeit(fn, dev, reps):
+    fn(); dev.sync()
+    dev.timer_start()
+    for _ in range(reps):
+        fn()
+    return dev.timer_stop() / reps
+
+
+def c3(args):
+    B, N, p = 512, 20000, 4
+    rng = np.random.default_rng(20241)
+    theta = np.array([28., 10., 8. / 3.])
+    W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, p)
+    x0 = init(np.array([-12., -5., 38.]) + 1e-3 * rng.standard_normal((B, 3)), 0.0, theta=theta)
+    prior = ra.ibm_init(20.0 / N, p, np.array([5e7] * 3))
+    plan = ra.SolvePlan(ra.ode.lorenz63, W, x0, 0.0, 20.0, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
+    ms = timeit(lambda: plan.mv(None), plan.dev, 2)
+    a = 3 * 3 * p * (p + 1) * 8
+    return {"config": "C3 Lorenz63 d=3 p=4 N=20000 B=512 solve_mv+kramer", "ms": ms, "traj_steps_per_s": B * N / ms * 1e3,
+            "hbm_frac_solve": a * B * N / (ms * 1e-3) / 8e12, "layout": plan.layout}
+
+
+def c4(args):
+    B, N = 1024, 800
+    rng = np.random.default_rng(20242)
+    u0 = np.concatenate([np.log([.2, .2, 3.]), [-1., 1.], [.1, .1]])
+    upars = u0 + np.array([0.01, 0.1, 0.01, 0.01, 0.01, 0.01, 0.01]) * rng.standard_normal((B, 7))
+    theta, x0v, sigma = np.exp(upars[:, :3]), upars[:, 3:5], upars[:, 5:]
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    X0 = init(x0v, 0., theta=theta)
+    prior = ra.ibm_init(40.0 / N, 3, sigma)
+    g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="standard")
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, X0, 0., 40., N, g, prior, theta=theta)
+    obs_t = np.linspace(0, 40, 41)
+    ind = obs_index(0., 40., N, obs_t)
+    Y = rng.standard_normal((41, 2))
+    def run():
+        plan.sim(20242)
+        return gauss_obs_logpost(plan, Y, ind, np.sqrt(0.005), upars=upars, n_prior=5)
+    ms = timeit(run, plan.dev, 5)
+    a = (2 * 2 * 3 * 4 + 2 * 3) * 8
+    lp = run().to_host()
+    return {"config": "C4 FN pseudo-marginal: 1024 draws/GPU, N=800, solve_sim+chkrebtii+logpost", "ms": ms,
+            "traj_steps_per_s": B * N / ms * 1e3, "hbm_frac_solve": a * B * N / (ms * 1e-3) / 8e12,
+            "finite": bool(np.all(np.isfinite(lp)))}
+
+
+def c5(args):
+    from scipy.linalg import block_diag
+    n_vars, n_deriv, N, B = 32, 5, args.c5_steps, args.c5_batch
+    rng = np.random.default_rng(20243)
+    lam = np.logspace(0, 3, n_vars)
+    A = -np.diag(lam) + 0.1 * rng.standard_normal((n_vars, n_vars)) / np.sqrt(n_vars)
+    Wb, _ = ra.utils.first_order_pad(lambda x, t: x, n_vars, n_deriv)
+    W = block_diag(*[w for w in Wb])[None]
+    prior = ra.indep_init(ra.ibm_init(1.0 / 2000, n_deriv, np.ones(n_vars)))
+    x0v = 1.0 + 0.01 * rng.standard_normal((B, n_vars))
+    X0 = np.zeros((B, n_vars, n_deriv)); X0[..., 0] = x0v; X0[..., 1] = x0v @ A.T
+    X0 = X0.reshape(B, 1, -1)
+    plan = ra.SolvePlan(ra.ode.linear_dense(n_vars, n_deriv), W, X0, 0.0, N / 2000.0, N,
+                        ra.interrogate.interrogate_kramer, prior, A=A)
+    dev = plan.dev
+    dev.profile_enable(True)
+    t0 = time.perf_counter(); plan.mv(None); dev.sync(); wall = time.perf_counter() - t0
+    prof = dict(dev.profile_last())
+    p, m = 160, 32
+    F = (12 + 2 / 3) * p ** 3 + 4 * m * p * p + 4 * m * m * p + (2 / 3) * m ** 3
+    ms = sum(prof.values())
+    return {"config": f"C5 dense p=160 m=32 N={N} B={B} solve_mv+kramer", "ms": ms, "kernels_ms": prof,
+            "traj_steps_per_s": B * N / ms * 1e3, "tflops": F * B * N / (ms * 1e-3) / 1e12,
+            "frac_fp64_peak_78.6TF": F * B * N / (ms * 1e-3) / 78.6e12, "wall_s": wall}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=["c3", "c4", "c5"])
+    ap.add_argument("--c5-batch", type=int, default=256)
+    ap.add_argument("--c5-steps", type=int, default=50)
+    args = ap.parse_args()
+    for w in args.which:
+        print(json.dumps({"c3": c3, "c4": c4, "c5": c5}[w](args)), flush=True)

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     from rodeo_amd import _lib
     assert ctypes.sizeof(_lib.SolveCfg) == 10 * 4 + 2 * 8 + 2 * 8
     assert ctypes.sizeof(_lib.SolveIn) == 5 * 16
-    assert ctypes.sizeof(_lib.SolveOut) == 5 * 8
+    assert ctypes.sizeof(_lib.SolveOut) == 6 * 8
     assert ctypes.sizeof(_lib.OpCfg) == 16
 
 
