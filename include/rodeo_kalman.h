@@ -74,6 +74,8 @@ extern "C" {
 #define RK_LAYOUT_BATCH_MINOR  0  /* mean_state (N+1, d, p, B), var_state (N+1, d, p, p, B)                  */
 #define RK_LAYOUT_TILE3        1  /* n_bstate = 3 only: var_state holds (N+1, B, d, 3, 4) doubles, row i of a
                                      block = [Sigma[i][0..2], mu[i]]; mean_state is not used (may be NULL)  */
+#define RK_LAYOUT_TILE4        3  /* n_bstate = 4 only: var_state holds (N+1, B, d, 20) doubles per block:
+                                     [Sigma row-major (16) | mu (4)]; mean_state is not used (may be NULL)   */
 #define RK_LAYOUT_TRAJ_MAJOR   2  /* dense large-block path: the reference's own layout with a leading batch
                                      axis, mean_state (B, N+1, d, p), var_state (B, N+1, d, p, p)            */
 
@@ -142,12 +144,14 @@ typedef struct {
 } rk_solve_out;
 
 /* Output layout the fused kernels use for this configuration and call (RK_MODE_*).  The MFMA-tile kernels
- * (n_bstate = 3, n_bmeas = 1, solve_mv / filter, kramer | schober | rodeo) write RK_LAYOUT_TILE3; everything else
+ * (n_bstate = 3 or 4, n_bmeas = 1, solve_mv / filter, kramer | schober | rodeo) write RK_LAYOUT_TILE3 / _TILE4, the dense
+ * path RK_LAYOUT_TRAJ_MAJOR; everything else
  * RK_LAYOUT_BATCH_MINOR.  The caller sizes and interprets out->mean_state / var_state accordingly.             */
 int rk_solve_layout(const rk_solve_cfg* cfg, int32_t mode, int32_t* layout);
 /* bytes of the output arrays for a configuration in the given layout (any pointer may be NULL);
  * RK_LAYOUT_TILE3: *mean_bytes = 0, *var_bytes = ((N+1) * B * d * 12 + 128 * ceil(B * d / 8)) * 8 -- the buffer MUST
- * have this size: behind the tiles sits a scratch tail (64 doubles per wave) that lanes without an output slot use. */
+ * have this size: behind the tiles sits a scratch tail (64 doubles per wave) that lanes without an output slot use.
+ * RK_LAYOUT_TILE4 likewise (20 doubles per tile + 128 per wave); always size tile buffers with this function.   */
 int rk_solve_sizes(const rk_solve_cfg* cfg, int32_t layout, size_t* mean_bytes, size_t* var_bytes);
 
 /* bytes of device scratch (rk_solve_out.workspace) the configuration needs; 0 for the small-block kernels */
@@ -164,7 +168,7 @@ int rk_solve_sim(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, co
  * per trajectory: the tail of the user log-posterior of docs/examples/parameter.md:188-210,331-354 (and of
  * src/rodeo/inference/basic.py:47-62 with a Gaussian obs_loglik).
  *   state: the solver output holding the path -- layout RK_LAYOUT_BATCH_MINOR: x_state / mean_state (N+1, d, p, B);
- *          layout RK_LAYOUT_TILE3: the tile buffer (N+1, B, d, 3, 4) (the mean is column 3);
+ *          layout RK_LAYOUT_TILE3 / RK_LAYOUT_TILE4: the tile buffer (the mean is column 3 / entries 16..19);
  *   obs (n_obs, d) row-major on device; obs_ind (n_obs) int32 on device (clamped to [0, N]);
  *   upars (n_prior, B) batch-minor or NULL (no prior term); out logpost (B).                              */
 int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n_block, int32_t n_bstate,

@@ -18,7 +18,7 @@ RHS_FITZHUGH_NAGUMO, RHS_LORENZ63, RHS_HIGHER_ORDER, RHS_LINEAR_DENSE = 1, 2, 3,
 FLAG_STORE_PRED = 1
 FLAG_BATCH_MINOR = 2
 MODE_FILTER, MODE_MV, MODE_SIM = 0, 1, 2
-LAYOUT_BATCH_MINOR, LAYOUT_TILE3, LAYOUT_TRAJ_MAJOR = 0, 1, 2
+LAYOUT_BATCH_MINOR, LAYOUT_TILE3, LAYOUT_TRAJ_MAJOR, LAYOUT_TILE4 = 0, 1, 2, 3
 COMM_UID_BYTES = 128
 
 

@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(64) interrogate_kernel(SolveArgs a, double t, 
 }
 
 // ---- Gaussian observation log-posterior reduction (docs/examples/parameter.md:188-210) ---------------------------
-__global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile, const double* x, const double* obs, const int32_t* obs_ind,
+__global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile, int tile_off, const double* x, const double* obs, const int32_t* obs_ind,
                                      int n_obs, double noise_sd, const double* upars, int n_prior, double prior_sd,
                                      double* out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,7 +311,7 @@ __global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile,
         ni = ni < 0 ? 0 : (ni > n_steps ? n_steps : ni);     // never index outside the (N+1)-long path
         const size_t n = (size_t)ni;
         for (int blk = 0; blk < D; ++blk) {
-            const double xv = tile ? x[((n * B + b) * D + blk) * 12 + 3]          // row 0 of [Sigma | mu]
+            const double xv = tile ? x[((n * B + b) * D + blk) * tile + tile_off]  // mu_0 inside the tile
                                    : x[((n * D + blk) * P + 0) * (size_t)B + b];
             const double zz = (obs[(size_t)k * D + blk] - xv) / noise_sd;
             acc += -0.5 * zz * zz - lsd - LOG_SQRT_2PI;       // scipy.stats.norm.logpdf
@@ -462,6 +462,11 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode);
 int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, int mode);
 size_t dense_ws_doubles(int p, int m);
 
+// MFMA-tile path for n_bstate = 4 (solve_tile4.hip)
+bool tile4_supported(const rk_solve_cfg* c, int mode);
+int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
+size_t tile4_doubles(const rk_solve_cfg* c);
+
 // MFMA-tile path (solve_tile3.hip)
 bool tile3_supported(const rk_solve_cfg* c, int mode);
 int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
@@ -476,7 +481,8 @@ int rk_solve_layout(const rk_solve_cfg* c, int32_t mode, int32_t* layout) {
     RK_REQUIRE(c && layout, RK_ERR_INVALID, "rk_solve_layout: null argument");
     RK_REQUIRE(mode >= RK_MODE_FILTER && mode <= RK_MODE_SIM, RK_ERR_INVALID, "rk_solve_layout: bad mode %d", mode);
     *layout = dense_supported(c, mode) ? RK_LAYOUT_TRAJ_MAJOR
-              : (tile3_supported(c, mode) ? RK_LAYOUT_TILE3 : RK_LAYOUT_BATCH_MINOR);
+              : (tile3_supported(c, mode) ? RK_LAYOUT_TILE3
+                 : (tile4_supported(c, mode) ? RK_LAYOUT_TILE4 : RK_LAYOUT_BATCH_MINOR));
     return RK_OK;
 }
 
@@ -498,6 +504,12 @@ int rk_solve_sizes(const rk_solve_cfg* c, int32_t layout, size_t* mean_bytes, si
         }
         return RK_OK;
     }
+    if (layout == RK_LAYOUT_TILE4) {
+        RK_REQUIRE(c->n_bstate == 4, RK_ERR_INVALID, "RK_LAYOUT_TILE4 needs n_bstate = 4");
+        if (mean_bytes) *mean_bytes = 0;
+        if (var_bytes) *var_bytes = tile4_doubles(c) * sizeof(double);
+        return RK_OK;
+    }
     RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR || layout == RK_LAYOUT_TRAJ_MAJOR, RK_ERR_INVALID, "unknown layout %d", layout);
     if (mean_bytes) *mean_bytes = m;
     if (var_bytes) *var_bytes = m * c->n_bstate;
@@ -510,7 +522,8 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     int rc = check_cfg(c, in);
     if (rc) return rc;
     const bool dense = dense_supported(c, mode);
-    const bool tile = !dense && tile3_supported(c, mode);
+    const bool tile4 = !dense && tile4_supported(c, mode);
+    const bool tile = !dense && (tile4 || tile3_supported(c, mode));
     RK_REQUIRE(out && out->var_state && (tile || out->mean_state), RK_ERR_INVALID,
                "out->mean_state / var_state must not be NULL");
     if (dense) {
@@ -531,6 +544,7 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     h->event_used = 0;
     SolveArgs a;
     make_args(c, in, out, a);
+    if (tile4) return tile4_solve(h, c, a, out->var_state, mode);
     if (tile) return tile3_solve(h, c, a, out->var_state, mode);
     rc = small_forward(h, c, a);
     if (rc) return rc;
@@ -577,14 +591,16 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
                          int32_t n_obs, double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
                          double* logpost) {
     RK_REQUIRE(h && x_state && obs && obs_ind && logpost, RK_ERR_INVALID, "rk_gauss_obs_logpost: null argument");
-    RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR || (layout == RK_LAYOUT_TILE3 && n_bstate == 3), RK_ERR_INVALID,
+    RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR || (layout == RK_LAYOUT_TILE3 && n_bstate == 3) ||
+                   (layout == RK_LAYOUT_TILE4 && n_bstate == 4), RK_ERR_INVALID,
                "rk_gauss_obs_logpost: bad layout %d for n_bstate %d", layout, n_bstate);
     RK_REQUIRE(n_traj >= 1 && n_obs >= 0 && n_block >= 1 && n_bstate >= 1 && n_steps >= 1, RK_ERR_INVALID,
                "rk_gauss_obs_logpost: bad dimension");
     RK_HIP(hipSetDevice(h->device));
     LaunchTimer t(h, "gauss_logpost_kernel");
     hipLaunchKernelGGL(gauss_logpost_kernel, dim3(div_up(n_traj, 64)), dim3(64), 0, h->stream, n_traj, n_steps, n_block,
-                       n_bstate, layout == RK_LAYOUT_TILE3 ? 1 : 0, x_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
+                       n_bstate, layout == RK_LAYOUT_TILE3 ? 12 : (layout == RK_LAYOUT_TILE4 ? 20 : 0),
+                       layout == RK_LAYOUT_TILE3 ? 3 : 16, x_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

@@ -10,8 +10,8 @@
 // with Q~ = diag(Q, 1), Qt = Q~^T, R~ = diag(R, 0).  The update (standard.py:93-102) with W~ = W + wgt_meas extended by
 // the offset a = mean_meas as a 4th entry (M-[3][:] = e_3) needs three more MFMAs:
 //        WS[c] = sum_k X[k] M-[k][c]   (c < 3: W~ Sigma- ; c = 3: W~ mu- + a = yhat)      column form
-//        Z[r]  = sum_k M-[k][r] X[k]   (= W~ Sigma- again, row form; stands in for Sigma- W~^T -- Sigma- is symmetric up
-//                                       to rounding, see DESIGN.md "symmetry use")
+//        Z[r]  = sum_{k<3} M-[r][k] X[k]  = Sigma- W~^T, row form, from the exact transpose M-^T = MF(Qt, U, R~^T)
+//                                       (using W~ Sigma- for it lets the antisymmetric rounding part of Sigma drift)
 //        S     = sum_{k<3} Z[k] X[k] + V
 //        M     = M- - (Z / S) WS       -> [ Sigma- - K (W~ Sigma-) | mu- - K yhat ]
 // HBM format ("tile layout"): per time step and tile the 3 x 4 block [Sigma | mu] row-major = 96 B, exactly the
@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     // per-lane constants in D layout
     const double Qt = in3 ? ld(a.Q, ((size_t)blk * P + c) * P + r, a.Q_b, a.B, b) : ((r == 3 && c == 3) ? 1.0 : 0.0);
     const double Rt = in3 ? ld(a.R, ((size_t)blk * P + r) * P + c, a.R_b, a.B, b) : 0.0;
+    const double RtT = in3 ? ld(a.R, ((size_t)blk * P + c) * P + r, a.R_b, a.B, b) : 0.0;   // R~^T
     const double Wr = r < 3 ? ld(a.W, (size_t)blk * P + r, a.W_b, a.B, b) : 0.0;          // W[k] at row k (all columns)
     const double Y0 = r < 3 ? ld(a.Q, ((size_t)blk * P + 0) * P + r, a.Q_b, a.B, b) : 0.0; // Q[0][k] at row k
     const double E0 = r == 0 ? 1.0 : 0.0;                                                  // selects row 0
@@ -87,10 +88,11 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     for (int n = 0; n < a.N; ++n) {
         // ---- predict (standard.py:57-59): U = (Q~ M)^T, M- = Q~ M Q~^T + R~; B0 = row 0 of Q~ M in every row ----
         // (a 4x4x4 fp64 MFMA blocks this wave's issue for ~17 cycles = 4 fp64 VALU ops, and nothing overlaps it --
-        //  profiles/r01_probe3_mfma_valu_serialize.log -- so the step is written with the fewest MFMAs: six)
+        //  profiles/r01_probe3_mfma_valu_serialize.log -- so the step is written with the fewest MFMAs: seven)
         const double U = MF(M, Qt, 0.0);
         const double B0 = MF(Y0, M, 0.0);
         const double Mp = MF(U, Qt, Rt);
+        const double MpT = MF(Qt, U, RtT);             // exact transpose of M-: Q~ M^T Q~^T + R~^T
         // ---- interrogation (interrogate.py): f and the block-diagonal Jacobian at mu- ----
         const double v_own = quad_bcast3(B0);          // mu-_0 of this tile's block, in all 16 lanes
         double X[D][P];
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         const double Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));       // rows: W_0 - J0, W_1, W_2, a
         // ---- update (standard.py:93-102) ----
         const double WS = MF(Xw, Mp, 0.0);                          // [W~ Sigma- | W~ mu- + a]   (column form)
-        const double Z0 = MF(Mp, Xw, 0.0) * m3;                     // Sigma- W~^T (row form), 0 in row 3
+        const double Z0 = MF(MpT, Xw * m3, 0.0);                    // Sigma- W~^T (standard.py:97; row form, 0 in row 3)
         double S = MF(Z0, Xw, 0.0);
         if constexpr (ITG == RK_INTERROGATE_RODEO) S = S + S;       // var_meas = W Sigma- W^T (interrogate.py:110-113)
         const double K = Z0 * fast_rcp(S);

@@ -39,6 +39,10 @@ def basic(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate
     for n in ind:
         if plan.layout == _lib.LAYOUT_TILE3:
             rows.append(plan.var_state.slice0_host(int(n))[..., 3])            # (B, d, 3) means
+        elif plan.layout == _lib.LAYOUT_TILE4:
+            rows.append(plan.var_state.slice0_host(int(n))[..., 16:])          # (B, d, 4) means
+        elif plan.layout == _lib.LAYOUT_TRAJ_MAJOR:
+            rows.append(plan.mean_state.to_host()[:, int(n)])
         else:
             rows.append(np.moveaxis(plan.mean_state.slice0_host(int(n)), -1, 0))   # (d, p, B) -> (B, d, p)
     ode_data = np.stack(rows, axis=1)                              # (B, n_obs, d, p)

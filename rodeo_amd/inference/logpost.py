@@ -38,7 +38,7 @@ def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10
         state, layout = plan.x_state, _lib.LAYOUT_BATCH_MINOR
     else:
         layout = plan.layout
-        state = plan.var_state if layout == _lib.LAYOUT_TILE3 else plan.mean_state
+        state = plan.var_state if layout in (_lib.LAYOUT_TILE3, _lib.LAYOUT_TILE4) else plan.mean_state
     d_obs, d_ind = dev.to_device(obs), dev.to_device(ind)
     d_up, k = None, 0
     if upars is not None:

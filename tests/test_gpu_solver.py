@@ -321,3 +321,50 @@ def test_rccl_single_rank_comm(ra):
     np.testing.assert_array_equal(recv.to_host(), np.arange(8.0))
     comm.close()
     dev.close()
+
+
+@pytest.mark.parametrize("prob,B,N", [("lorenz", 1, 50), ("lorenz", 5, 83), ("fitz4", 3, 40), ("fitz4", 9, 97),
+                                      ("higher", 6, 66), ("higher", 1, 17)])
+@pytest.mark.parametrize("name", ["kramer", "rodeo"])
+def test_tile4_path_equals_batch_minor_and_oracle(ra, prob, B, N, name):
+    """p = 4 MFMA-tile kernels (n_block = 3, 2, 1; ragged tile counts and chunk tails) vs lane-per-trajectory vs oracle."""
+    from rodeo_amd import _lib
+    g, o = _itg(ra, name)
+    rng = np.random.default_rng(B * 1000 + N)
+    if prob == "lorenz":
+        theta = np.array([28., 10., 8. / 3.]) * np.exp(0.01 * rng.standard_normal((B, 3)))
+        W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, 4)
+        x0 = init(np.array([-12., -5., 38.]) + 0.1 * rng.standard_normal((B, 3)), 0.0, theta=theta)
+        t_max = N * 1e-3
+        prior = ra.ibm_init(1e-3, 4, np.array([5e7] * 3))
+        dode, oode, kw = ra.ode.lorenz63, odes.lorenz63, dict(theta=theta)
+    elif prob == "fitz4":
+        s = fitz_problem(ra, N=N, t_max=N * 0.05, sigma=.1, p=4, B=B, seed=N)
+        W, x0, prior, t_max = s["W"], s["x0"], s["prior"], s["t_max"]
+        dode, oode, kw = ra.ode.fitzhugh_nagumo, odes.fitzhugh_nagumo, dict(theta=s["theta"])
+    else:
+        W = np.array([[[0., 0., 1., 0.]]])
+        x0 = np.tile(np.array([[-1., 0., 1., 0.]]), (B, 1, 1)) + 0.01 * rng.standard_normal((B, 1, 4))
+        t_max = N * 0.05
+        prior = ra.ibm_init(0.05, 4, np.array([.01]))
+        dode, oode, kw = ra.ode.higher_order, odes.higher_order, {}
+    args = (W, x0, 0.0, t_max, N)
+    pt = ra.SolvePlan(dode, *args, g, prior, **kw)
+    pt.mv(None)
+    assert pt.layout == _lib.LAYOUT_TILE4
+    m, v = pt.state_host()
+    pb = ra.SolvePlan(dode, *args, g, prior, batch_minor=True, **kw)
+    pb.mv(None)
+    m2, v2 = pb.state_host()
+    mo, vo = scan.solve_mv(None, oode, *args, o, prior, **kw)
+    assert m.shape == mo.shape and v.shape == vo.shape
+    sm = np.max(np.abs(mo), axis=(0, 1, 2))                           # per derivative order
+    sd = np.sqrt(np.max(np.abs(np.einsum("bnkii->bnki", vo)), axis=(0, 1, 2)))   # per-component sd scale
+    sv = sd[:, None] * sd[None, :]                                    # covariance scale (scale-invariant metric)
+    for mm, vv in ((m, v), (m2, v2)):
+        assert np.max(np.abs(mm - mo) / sm) < 1e-8
+        assert np.max(np.abs(vv - vo) / sv) < 1e-7
+    pt.filter(None)
+    mf, vf = pt.state_host()
+    fo = scan.solve_filter(None, oode, *args, o, *prior, **kw)
+    assert np.max(np.abs(mf - fo["state_filt"][0]) / sm) < 1e-8
