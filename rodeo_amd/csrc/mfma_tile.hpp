@@ -41,6 +41,11 @@ __device__ __forceinline__ double dpp64_banks(double old, double x) {
 __device__ __forceinline__ double pair_block0(double x) { return dpp64_banks<0x124, 0xA>(x, x); }   // odd g <- g-1
 __device__ __forceinline__ double pair_block1(double x) { return dpp64_banks<0x12C, 0x5>(x, x); }   // even g <- g+1
 
+// value of the OTHER block of this lane's trajectory (n_block = 2)
+__device__ __forceinline__ double pair_other(double x) {
+    return dpp64_banks<0x124, 0xA>(dpp64_banks<0x12C, 0x5>(x, x), x);
+}
+
 // broadcast column 3 of every (r, g) quad to its four lanes
 __device__ __forceinline__ double quad_bcast3(double x) { return dpp64<0xFF>(x); }
 // value held by the same (r, c) lane of tile g-1 / g+1 (cyclic within the 16-lane row)

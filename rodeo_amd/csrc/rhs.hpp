@@ -45,6 +45,24 @@ struct FitzHughNagumo {
         J[0][0] = th[2] * (1.0 - V * V);
         J[1][0] = -th[1] / th[2];
     }
+    // Optional "tile form" used by the MFMA-tile forward kernel (one (trajectory, block) per 16 lanes): every lane
+    // evaluates only ITS block's f_b and J_b0 from own = X[b][0] and oth = X[1-b][0] through per-lane coefficients,
+    //     f_b = k0 own + k1 own^3 + k2 oth + k3 ,   d f_b / d X[b][0] = k4 + k5 own^2 ,
+    // instead of both blocks plus selects (11 fewer VALU instructions per step).  Same function as f / fjac; the
+    // association differs from the reference expression at rounding level (c V - (c/3) V^3 + c R).
+    static constexpr bool HAS_TILE_FORM = true;
+    static constexpr int NTILEK = 6;
+    __device__ __forceinline__ static void tile_consts(int blk, const double (&th)[NTHETA], double (&k)[NTILEK]) {
+        const double a = th[0], b = th[1], c = th[2];
+        if (blk == 0) { k[0] = c; k[1] = -c / 3; k[2] = c; k[3] = 0.0; k[4] = c; k[5] = -c; }
+        else { k[0] = -b / c; k[1] = 0.0; k[2] = -1 / c; k[3] = a / c; k[4] = -b / c; k[5] = 0.0; }
+    }
+    __device__ __forceinline__ static void tile_eval(const double (&k)[NTILEK], double own, double oth, double,
+                                                     double& f, double& J0) {
+        const double o2 = own * own;
+        f = fma(k[1], o2 * own, fma(k[0], own, fma(k[2], oth, k[3])));
+        J0 = fma(k[5], o2, k[4]);
+    }
 };
 
 // Lorenz63, docs/examples/lorenz.md:85-92.  theta = (rho, sigma, beta).
@@ -73,6 +91,7 @@ struct Lorenz63 {
         J[1][0] = -1.0;
         J[2][0] = -th[2];
     }
+    static constexpr bool HAS_TILE_FORM = false;
 };
 
 // Second-order ODE of Chkrebtii et al, docs/examples/higher_order.md:47-59:  x'' = sin(2t) - x.
@@ -93,6 +112,7 @@ struct HigherOrder {
         for (int j = 0; j < P; ++j) J[0][j] = 0.0;
         J[0][0] = -1.0;
     }
+    static constexpr bool HAS_TILE_FORM = false;
 };
 
 }  // namespace rk

@@ -73,6 +73,8 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     double th[RHS::NTHETA];
 #pragma unroll
     for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
+    double tk[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (RHS::HAS_TILE_FORM && D == 2) RHS::tile_consts(blk, th, tk);
 
     // M_0 = [0 | ode_init ; 0 1]   (solve.py:53-54)
     double M = r < 3 ? (c == 3 ? ld(a.x0, (size_t)blk * P + r, a.x0_b, a.B, b) : 0.0) : (c == 3 ? 1.0 : 0.0);
@@ -95,30 +97,36 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         const double MpT = MF(Qt, U, RtT);             // exact transpose of M-: Q~ M^T Q~^T + R~^T
         // ---- interrogation (interrogate.py): f and the block-diagonal Jacobian at mu- ----
         const double v_own = quad_bcast3(B0);          // mu-_0 of this tile's block, in all 16 lanes
-        double X[D][P];
-#pragma unroll
-        for (int bb = 0; bb < D; ++bb)
-#pragma unroll
-            for (int j = 0; j < P; ++j) X[bb][j] = 0.0;
-        if constexpr (D == 1) {
-            X[0][0] = v_own;
-        } else {
-            X[0][0] = pair_block0(v_own);
-            X[1][0] = pair_block1(v_own);
-        }
         const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
-        double f[D], J[D][P];
-        if constexpr (ITG == RK_INTERROGATE_KRAMER) {
-            RHS::template fjac<P>(X, t, th, f, J);
+        double fb, J0;
+        if constexpr (RHS::HAS_TILE_FORM && D == 2) {
+            RHS::tile_eval(tk, v_own, pair_other(v_own), t, fb, J0);
+            if constexpr (ITG != RK_INTERROGATE_KRAMER) J0 = 0.0;
         } else {
-            RHS::template f<P>(X, t, th, f);
+            double X[D][P];
 #pragma unroll
             for (int bb = 0; bb < D; ++bb)
 #pragma unroll
-                for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+                for (int j = 0; j < P; ++j) X[bb][j] = 0.0;
+            if constexpr (D == 1) {
+                X[0][0] = v_own;
+            } else {
+                X[0][0] = pair_block0(v_own);
+                X[1][0] = pair_block1(v_own);
+            }
+            double f[D], J[D][P];
+            if constexpr (ITG == RK_INTERROGATE_KRAMER) {
+                RHS::template fjac<P>(X, t, th, f, J);
+            } else {
+                RHS::template f<P>(X, t, th, f);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+            }
+            fb = f[0]; J0 = J[0][0];
+            if constexpr (D == 2) { fb = blk == 0 ? f[0] : f[1]; J0 = blk == 0 ? J[0][0] : J[1][0]; }
         }
-        double fb = f[0], J0 = J[0][0];
-        if constexpr (D == 2) { fb = blk == 0 ? f[0] : f[1]; J0 = blk == 0 ? J[0][0] : J[1][0]; }
         // X_w[k] (row form): W~_k = W_k - J_k for k < 3 (solve.py:79, interrogate.py:80), a = -f + J mu- at k = 3
         const double a_meas = fma(J0, v_own, -fb);                  // mean_meas (interrogate.py:81-82)
         const double Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));       // rows: W_0 - J0, W_1, W_2, a
