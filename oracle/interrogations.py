@@ -88,7 +88,10 @@ def interrogate_chkrebtii(key, ode_fun, ode_weight, t, mean_state_pred, var_stat
     elif kalman_type == "square-root":
         # reference quirk (interrogate.py:36-42): var_meas = W L has shape (m, p), and the draw is mu + (W L) z
         var_meas = np.matmul(ode_weight, var_state_pred)
-        x_state = mean_state_pred + np.matmul(var_meas, z[..., None])[..., 0]
+        # factors are unique only up to column signs (QR): draws use the sign-normalised factor (diag >= 0) so that the
+        # device and this oracle sample the same path whatever signs their Householder steps produce
+        sgn = np.where(np.einsum("...ii->...i", var_state_pred) < 0, -1.0, 1.0)
+        x_state = mean_state_pred + np.matmul(var_meas, (sgn * z)[..., None])[..., 0]
     else:
         raise NotImplementedError
     mean_meas = -ode_fun(x_state, t, **params)

@@ -147,7 +147,8 @@ def solve_sim(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interro
         else:
             z = counter_rng.normals(key, traj, n, n_block, n_bstate, counter_rng.PURPOSE_SMOOTH)
         if kalman_type == "square-root":
-            F = var                                       # already a factor
+            # already a factor; column signs normalised (diag >= 0) -- see interrogations.interrogate_chkrebtii
+            F = var * np.where(np.einsum("...ii->...i", var) < 0, -1.0, 1.0)[..., None, :]
         else:
             F = psd_factor(var)
         return mean + np.matmul(F, z[..., None])[..., 0]

@@ -462,6 +462,9 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode);
 int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, int mode);
 size_t dense_ws_doubles(int p, int m);
 
+// fused square-root solver (solve_sqrt.hip)
+int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode);
+
 // MFMA-tile path for n_bstate = 4 (solve_tile4.hip)
 bool tile4_supported(const rk_solve_cfg* c, int mode);
 int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
@@ -537,13 +540,14 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED) || (out->mean_pred && out->var_pred), RK_ERR_INVALID,
                "RK_FLAG_STORE_PRED needs out->mean_pred / var_pred");
     RK_REQUIRE(mode != 2 || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");
-    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED,
-               "kalman_type=square-root is not available in the fused solver yet");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD || !(c->flags & RK_FLAG_STORE_PRED), RK_ERR_UNSUPPORTED,
+               "RK_FLAG_STORE_PRED is not available with kalman_type=square-root");
     RK_HIP(hipSetDevice(h->device));
     h->prof.clear();
     h->event_used = 0;
     SolveArgs a;
     make_args(c, in, out, a);
+    if (c->kalman_type == RK_KALMAN_SQRT) return sqrt_solve(h, c, a, mode);
     if (tile4) return tile4_solve(h, c, a, out->var_state, mode);
     if (tile) return tile3_solve(h, c, a, out->var_state, mode);
     rc = small_forward(h, c, a);

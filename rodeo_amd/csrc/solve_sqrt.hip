@@ -1,0 +1,267 @@
+// Fused solver kernels for kalman_type = "square-root" (src/rodeo/solve.py:140-141 selecting
+// src/rodeo/kalmantv/square_root.py): same time loops as solve_small.hip, with every variance replaced by a lower
+// square-root factor and add_sqrt (Householder QR, src/rodeo/utils.py:10-24) in place of the variance sums.
+//   prior_pars = (Q, chol(R))  as in docs/examples/higher_order.md:106-125
+//   outputs: mean (N+1, d, p, B) and the FACTORS (N+1, d, p, p, B), batch-minor, like the reference's return values.
+// One lane per trajectory forward (the interrogation couples the blocks), one lane per (block, trajectory) backward.
+// Reference quirks kept because they define the reference's numbers in this mode (oracle/interrogations.py has the
+// same): interrogate_rodeo hands W L- W^T and interrogate_chkrebtii hands W L- (1 x p) to the update as the
+// "factor" of var_meas (src/rodeo/interrogate.py:36-42, 110-113).  One quirk is NOT kept: solve_sim's draws use
+// N(mean, L L^T) (the reference passes the factor where jax expects a covariance, solve.py:179).
+#include "common.hpp"
+#include "kalman_small.hpp"
+#include "philox.hpp"
+#include "rhs.hpp"
+#include "solve_args.hpp"
+#include "sqrt_small.hpp"
+
+namespace rk {
+
+template <class RHS, int P, int ITG>
+__global__ void __launch_bounds__(64) fwd_sqrt_kernel(SolveArgs a) {
+    constexpr int D = RHS::D;
+    constexpr int KV = ITG == RK_INTERROGATE_CHKREBTII ? P : 1;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const size_t B = (size_t)a.B;
+    double W[D][P], th[RHS::NTHETA], mu[D][P], L[D][P][P];
+#pragma unroll
+    for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
+#pragma unroll
+    for (int blk = 0; blk < D; ++blk)
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const size_t em = (size_t)blk * P + i;
+            W[blk][i] = ld(a.W, em, a.W_b, a.B, b);
+            mu[blk][i] = ld(a.x0, em, a.x0_b, a.B, b);
+            a.mean[em * B + b] = mu[blk][i];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                L[blk][i][j] = 0.0;
+                a.var[(em * P + j) * B + b] = 0.0;
+            }
+        }
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+    const size_t mstride = (size_t)D * P * B, vstride = (size_t)D * P * P * B;
+    for (int n = 0; n < a.N; ++n) {
+        double mup[D][P], Lp[D][P][P];
+#pragma unroll
+        for (int blk = 0; blk < D; ++blk) {
+            double Q[P][P], LR[P][P];
+            load_block_consts<P>(a, blk, b, Q, LR);
+            sqrt_predict<P>(Q, LR, mu[blk], L[blk], mup[blk], Lp[blk]);                  // square_root.py:56-57
+        }
+        const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;  // solve.py:74
+        // ---- interrogation (interrogate.py) with the factor standing where the reference puts it ----
+        double f[D], wgt[D][P], am[D], vm[D][KV];
+        if constexpr (ITG == RK_INTERROGATE_KRAMER) {
+            double J[D][P];
+            RHS::template fjac<P>(mup, t, th, f, J);
+#pragma unroll
+            for (int blk = 0; blk < D; ++blk) {
+                am[blk] = -f[blk] + dot<P>(J[blk], mup[blk]);
+                vm[blk][0] = 0.0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) wgt[blk][j] = -J[blk][j];
+            }
+        } else {
+            double WL[D][P];
+#pragma unroll
+            for (int blk = 0; blk < D; ++blk)
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    double s = W[blk][0] * Lp[blk][0][j];
+#pragma unroll
+                    for (int i = 1; i < P; ++i) s = fma(W[blk][i], Lp[blk][i][j], s);
+                    WL[blk][j] = s;
+                }
+            if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
+                // interrogate.py:36-42: var_meas = W L- (1 x p) ; x = mu- + (W L-) . z  (one scalar added to every entry)
+                double xs[D][P];
+#pragma unroll
+                for (int blk = 0; blk < D; ++blk) {
+                    double z[P];
+                    normals<P>(a.seed, traj, (uint32_t)n, (uint32_t)blk, PURPOSE_INTERROGATE, z);
+#pragma unroll
+                    for (int j = 0; j < P; ++j) z[j] = Lp[blk][j][j] < 0.0 ? -z[j] : z[j];   // sign-normalised factor
+                    const double shift = dot<P>(WL[blk], z);
+#pragma unroll
+                    for (int j = 0; j < P; ++j) { xs[blk][j] = mup[blk][j] + shift; vm[blk][j] = WL[blk][j]; }
+                }
+                RHS::template f<P>(xs, t, th, f);
+            } else {
+                RHS::template f<P>(mup, t, th, f);
+#pragma unroll
+                for (int blk = 0; blk < D; ++blk)
+                    vm[blk][0] = ITG == RK_INTERROGATE_RODEO ? dot<P>(WL[blk], W[blk]) : 0.0;   // interrogate.py:110-113 / :60
+            }
+#pragma unroll
+            for (int blk = 0; blk < D; ++blk) {
+                am[blk] = -f[blk];
+#pragma unroll
+                for (int j = 0; j < P; ++j) wgt[blk][j] = 0.0;
+            }
+        }
+        double* mo = a.mean + (size_t)(n + 1) * mstride + b;
+        double* vo = a.var + (size_t)(n + 1) * vstride + b;
+#pragma unroll
+        for (int blk = 0; blk < D; ++blk) {
+            double Wm[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) Wm[j] = W[blk][j] + wgt[blk][j];                   // solve.py:79
+            sqrt_update_m1<P, KV>(Wm, am[blk], vm[blk], mup[blk], Lp[blk], mu[blk], L[blk]);
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const size_t em = (size_t)blk * P + i;
+                mo[em * B] = mu[blk][i];
+#pragma unroll
+                for (int j = 0; j < P; ++j) vo[(em * P + j) * B] = L[blk][i][j];
+            }
+        }
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void load_state(const SolveArgs& a, int n, int blk, int b, double (&mf)[P],
+                                           double (&Lf)[P][P]) {
+    const size_t B = (size_t)a.B;
+    const double* mi = a.mean + ((size_t)n * a.D + blk) * P * B + b;
+    const double* vi = a.var + ((size_t)n * a.D + blk) * P * P * B + b;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        mf[i] = mi[(size_t)i * B];
+#pragma unroll
+        for (int j = 0; j < P; ++j) Lf[i][j] = vi[((size_t)i * P + j) * B];
+    }
+}
+
+// backward: SIM = false -> smooth_mv (square_root.py:209-219), SIM = true -> smooth_sim + draw (square_root.py:252-261)
+template <int P, bool SIM>
+__global__ void __launch_bounds__(64) bwd_sqrt_kernel(SolveArgs a) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.B * a.D) return;
+    const int blk = l / a.B, b = l - blk * a.B;
+    const size_t B = (size_t)a.B;
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+    double Q[P][P], LR[P][P];
+    load_block_consts<P>(a, blk, b, Q, LR);
+    double ms[P], Ls[P][P], xn[P];
+    load_state<P>(a, a.N, blk, b, ms, Ls);                       // carry = filt[N]
+    if (SIM) {
+        double z[P];
+        normals<P>(a.seed, traj, (uint32_t)a.N, (uint32_t)blk, PURPOSE_SMOOTH, z);
+#pragma unroll
+        for (int j = 0; j < P; ++j) z[j] = Ls[j][j] < 0.0 ? -z[j] : z[j];        // draws use the factor with diag >= 0
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            double s = ms[i];
+#pragma unroll
+            for (int k = 0; k < P; ++k) s = fma(Ls[i][k], z[k], s);
+            xn[i] = s;
+            a.x[(((size_t)a.N * a.D + blk) * P + i) * B + b] = s;
+        }
+    }
+    for (int n = a.N - 1; n >= 1; --n) {
+        double mf[P], Lf[P][P], mp[P], Lp[P][P], G[P][P], JL[P][P];
+        load_state<P>(a, n, blk, b, mf, Lf);
+        sqrt_predict<P>(Q, LR, mf, Lf, mp, Lp);                  // pred[n+1] re-evaluated from filt[n]
+        sqrt_gain<P>(Q, Lf, Lp, G, JL);
+        double dm[P], gm[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) dm[i] = (SIM ? xn[i] : ms[i]) - mp[i];
+        mv<P, P>(G, dm, gm);
+        if (!SIM) {
+            double both[P][2 * P], GA[P][2 * P];
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int j = 0; j < P; ++j) { both[i][j] = Ls[i][j]; both[i][P + j] = LR[i][j]; }
+            mm<P, P, 2 * P>(G, both, GA);
+            add_sqrt<P, 2 * P, P>(GA, JL, Ls);                   // square_root.py:217-218
+            double* mo = a.mean + ((size_t)n * a.D + blk) * P * B + b;
+            double* vo = a.var + ((size_t)n * a.D + blk) * P * P * B + b;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                ms[i] = mf[i] + gm[i];
+                mo[(size_t)i * B] = ms[i];
+#pragma unroll
+                for (int j = 0; j < P; ++j) vo[((size_t)i * P + j) * B] = Ls[i][j];
+            }
+        } else {
+            double GR[P][P], Lsim[P][P], z[P];
+            mm<P, P, P>(G, LR, GR);
+            add_sqrt<P, P, P>(GR, JL, Lsim);                     // square_root.py:259-260
+            normals<P>(a.seed, traj, (uint32_t)n, (uint32_t)blk, PURPOSE_SMOOTH, z);
+#pragma unroll
+            for (int j = 0; j < P; ++j) z[j] = Lsim[j][j] < 0.0 ? -z[j] : z[j];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                double s = mf[i] + gm[i];
+#pragma unroll
+                for (int k = 0; k < P; ++k) s = fma(Lsim[i][k], z[k], s);
+                xn[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i) a.x[(((size_t)n * a.D + blk) * P + i) * B + b] = xn[i];
+        }
+    }
+    if (SIM) {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            a.x[((size_t)blk * P + i) * B + b] = a.mean[((size_t)blk * P + i) * B + b];   // x[0] = ode_init
+    }
+}
+
+template <class RHS, int P>
+static int launch_fwd_sqrt_p(rk_handle h, const SolveArgs& a, int itg) {
+    const dim3 grid(div_up(a.B, 64)), block(64);
+    LaunchTimer t(h, "fwd_sqrt_kernel");
+    switch (itg) {
+        case RK_INTERROGATE_RODEO: hipLaunchKernelGGL((fwd_sqrt_kernel<RHS, P, RK_INTERROGATE_RODEO>), grid, block, 0, h->stream, a); break;
+        case RK_INTERROGATE_SCHOBER: hipLaunchKernelGGL((fwd_sqrt_kernel<RHS, P, RK_INTERROGATE_SCHOBER>), grid, block, 0, h->stream, a); break;
+        case RK_INTERROGATE_KRAMER: hipLaunchKernelGGL((fwd_sqrt_kernel<RHS, P, RK_INTERROGATE_KRAMER>), grid, block, 0, h->stream, a); break;
+        case RK_INTERROGATE_CHKREBTII: hipLaunchKernelGGL((fwd_sqrt_kernel<RHS, P, RK_INTERROGATE_CHKREBTII>), grid, block, 0, h->stream, a); break;
+        default: set_error("unknown interrogate id %d", itg); return RK_ERR_UNSUPPORTED;
+    }
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+template <class RHS>
+static int launch_fwd_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
+    RK_REQUIRE(c->n_block == RHS::D && c->n_bmeas == 1, RK_ERR_UNSUPPORTED,
+               "rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, RHS::D, c->n_block, c->n_bmeas);
+    switch (c->n_bstate) {
+        case 2: return launch_fwd_sqrt_p<RHS, 2>(h, a, c->interrogate);
+        case 3: return launch_fwd_sqrt_p<RHS, 3>(h, a, c->interrogate);
+        case 4: return launch_fwd_sqrt_p<RHS, 4>(h, a, c->interrogate);
+    }
+    set_error("square-root solver supports n_bstate in [2, 4], got %d", c->n_bstate);
+    return RK_ERR_UNSUPPORTED;
+}
+
+int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode) {
+    int rc;
+    switch (c->rhs_id) {
+        case RK_RHS_FITZHUGH_NAGUMO: rc = launch_fwd_sqrt<FitzHughNagumo>(h, c, a); break;
+        case RK_RHS_LORENZ63: rc = launch_fwd_sqrt<Lorenz63>(h, c, a); break;
+        case RK_RHS_HIGHER_ORDER: rc = launch_fwd_sqrt<HigherOrder>(h, c, a); break;
+        default: set_error("unknown rhs_id %d for the square-root solver", c->rhs_id); return RK_ERR_UNSUPPORTED;
+    }
+    if (rc || mode == RK_MODE_FILTER) return rc;
+    const dim3 grid(div_up(a.B * a.D, 64)), block(64);
+    LaunchTimer t(h, mode == RK_MODE_SIM ? "bwd_sqrt_sim_kernel" : "bwd_sqrt_mv_kernel");
+#define RK_SQ(P_)                                                                                        \
+    case P_:                                                                                             \
+        if (mode == RK_MODE_SIM) hipLaunchKernelGGL((bwd_sqrt_kernel<P_, true>), grid, block, 0, h->stream, a);  \
+        else hipLaunchKernelGGL((bwd_sqrt_kernel<P_, false>), grid, block, 0, h->stream, a);             \
+        break;
+    switch (c->n_bstate) { RK_SQ(2) RK_SQ(3) RK_SQ(4) }
+#undef RK_SQ
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+}  // namespace rk

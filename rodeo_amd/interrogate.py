@@ -76,7 +76,8 @@ def interrogate_kramer(key, ode_fun, ode_weight, t, mean_state_pred, var_state_p
 def interrogate_chkrebtii(key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, kalman_type, **params):
     """src/rodeo/interrogate.py:13-47: x ~ N(mu-, Sigma-), mean_meas = -f(x), var_meas = W Sigma- W^T."""
     if kalman_type == "square-root":
-        raise NotImplementedError("interrogate_chkrebtii(kalman_type='square-root') is not available on the device yet")
+        raise NotImplementedError("standalone interrogate_chkrebtii(kalman_type='square-root') is only available fused "
+                                  "into solve_mv / solve_sim")
     if kalman_type != "standard":
         raise NotImplementedError                       # src/rodeo/interrogate.py:43-44
     return _run(_lib.INTERROGATE_CHKREBTII, key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, params)

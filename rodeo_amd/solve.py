@@ -78,6 +78,8 @@ class SolvePlan:
                                 "(src/rodeo/interrogate.py:13-15)")
             if kt not in _KALMAN:
                 raise NotImplementedError                # src/rodeo/interrogate.py:43-44
+            if kt != kalman_type:
+                raise NotImplementedError("interrogate_chkrebtii's kalman_type must equal the solver's kalman_type")
         prior_weight, prior_var = prior_pars
         W = np.asarray(ode_weight, dtype=np.float64)
         x0 = np.asarray(ode_init, dtype=np.float64)

@@ -368,3 +368,61 @@ def test_tile4_path_equals_batch_minor_and_oracle(ra, prob, B, N, name):
     mf, vf = pt.state_host()
     fo = scan.solve_filter(None, oode, *args, o, *prior, **kw)
     assert np.max(np.abs(mf - fo["state_filt"][0]) / sm) < 1e-8
+
+
+def _chol_prior(prior):
+    return prior[0], np.linalg.cholesky(prior[1])
+
+
+def _sq(L):
+    return L @ np.swapaxes(L, -1, -2)
+
+
+@pytest.mark.parametrize("name", ["kramer", "schober", "rodeo", "chkrebtii"])
+def test_square_root_solver_parity(ra, name):
+    """kalman_type='square-root' (docs/examples/higher_order.md:106-142): factors compared as L L^T against the oracle's
+    square-root scan, and against the standard filter's variances (same posterior in exact arithmetic)."""
+    B, N = 5, 60
+    s = fitz_problem(ra, N=N, t_max=3.0, sigma=.1, B=B, seed=9)
+    pr = _chol_prior(s["prior"])
+    if name == "chkrebtii":
+        g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="square-root")
+        o = functools.partial(oi.interrogate_chkrebtii, kalman_type="square-root")
+    else:
+        g, o = _itg(ra, name)
+    args = (s["W"], s["x0"], 0.0, 3.0, N)
+    m, L = ra.solve_mv(5, ra.ode.fitzhugh_nagumo, *args, g, pr, kalman_type="square-root", theta=s["theta"])
+    mo, Lo = scan.solve_mv(5, odes.fitzhugh_nagumo, *args, o, pr, kalman_type="square-root", theta=s["theta"])
+    assert m.shape == (B, N + 1, 2, 3) and L.shape == (B, N + 1, 2, 3, 3)
+    assert np.max(np.abs(m - mo)) < 1e-8
+    _vclose(_sq(L), _sq(Lo), 1e-7)
+    if name in ("kramer", "schober"):                   # var_meas = 0: identical posterior to the standard filter
+        m2, v2 = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+        assert np.max(np.abs(m - m2)) < 1e-7
+        _vclose(_sq(L), v2, 1e-6)
+    x = ra.solve_sim(5, ra.ode.fitzhugh_nagumo, *args, g, pr, kalman_type="square-root", theta=s["theta"])
+    xo = scan.solve_sim(5, odes.fitzhugh_nagumo, *args, o, pr, kalman_type="square-root", theta=s["theta"])
+    assert x.shape == (B, N + 1, 2, 3) and np.all(np.isfinite(x))
+    np.testing.assert_array_equal(x[:, 0], s["x0"])
+    if name in ("rodeo", "chkrebtii"):
+        # var_meas > 0: full-rank factors are unique once their diagonal signs are fixed -> the same sample path
+        assert np.max(np.abs(x - xo)) < 1e-6
+    else:
+        # exact measurement (var_meas = 0): the filtered factor is rank deficient, a lower factor is then not unique and
+        # two QR implementations draw different (equally valid) paths; check the draw against the smoothed moments
+        sd = np.sqrt(np.einsum("bnkii->bnki", _sq(L)))
+        assert np.max(np.abs(x - m)[:, 1:] / (sd[:, 1:] + 1e-12)) < 8.0
+
+
+def test_square_root_higher_order_example(ra):
+    """The docs' square-root run (higher_order.md:109-125): n_deriv = 4 second-order ODE, vs the analytic solution."""
+    W = np.array([[[0., 0., 1., 0.]]]); x0 = np.array([[-1., 0., 1., 0.]])
+    N = 400
+    Q, R = ra.ibm_init(10.0 / N, 4, np.array([.001]))
+    m, L = ra.solve_mv(None, ra.ode.higher_order, W, x0, 0.0, 10.0, N, ra.interrogate.interrogate_kramer,
+                       (Q, np.linalg.cholesky(R)), kalman_type="square-root")
+    assert m.shape == (N + 1, 1, 4) and np.all(np.isfinite(L))
+    assert abs(np.max(np.abs(m[:, 0, 0] - odes.higher_order_exact(np.linspace(0, 10, N + 1)))) - 1.04e-4) < 2e-5
+    mo, Lo = scan.solve_mv(None, odes.higher_order, W, x0, 0.0, 10.0, N, oi.interrogate_kramer,
+                           (Q, np.linalg.cholesky(R)), kalman_type="square-root")
+    assert np.max(np.abs(m - mo)) < 1e-8
