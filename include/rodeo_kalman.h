@@ -60,6 +60,7 @@ extern "C" {
 #define RK_RHS_LORENZ63         2   /* docs/examples/lorenz.md:85-92; theta = (rho, sigma, beta); n_block = 3 */
 #define RK_RHS_HIGHER_ORDER     3   /* docs/examples/higher_order.md:47-59; x'' = sin 2t - x; n_block = 1     */
 #define RK_RHS_LINEAR_DENSE     4   /* x' = A x as one dense block (prior/indep_init.py); theta = A row-major */
+#define RK_RHS_USER_BASE        1000 /* ids returned by rk_register_rhs_source start here                     */
 
 /* flags for rk_solve_cfg.flags */
 #define RK_FLAG_STORE_PRED   1    /* also write the predicted moments (solve.py:93-96 state_pred)            */
@@ -102,6 +103,17 @@ int         rk_timer_stop(rk_handle h, double* elapsed_ms);     /* records, sync
  * Enabled with rk_profile_enable(h, 1); names/ms arrays of capacity cap are filled, *n = number of launches. */
 int         rk_profile_enable(rk_handle h, int on);
 int         rk_profile_last(rk_handle h, int cap, const char** names, double* ms, int* n);
+
+/* ---- user-supplied ODE right-hand sides ------------------------------------------------------------------------
+ * The `ode_fun(X, t, **params)` callable of src/rodeo/solve.py:218 (and its jax.jacfwd, src/rodeo/interrogate.py:76)
+ * for an ODE that is not built in: HIP source defining, inside namespace rk, a struct with the interface of
+ * rodeo_amd/csrc/rhs.hpp (D, NTHETA, NDEP, f<P>, fjac<P>) -- or a scalar-generic `rhs<T, P>` used through
+ * "AutoJac<Name>" (forward-mode duals, rodeo_amd/csrc/dual.hpp).  type_name is that C++ type.  The kernels are
+ * compiled with hiprtc on first use per (n_bstate, interrogation); n_bmeas = 1, kalman_type = standard.
+ * rk_rhs_compile_check compiles without loading (needs no GPU) and reports compiler errors via rk_last_error().   */
+int rk_register_rhs_source(const char* type_name, const char* source, int32_t n_block, int32_t n_theta,
+                           int32_t* rhs_id);
+int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate);
 
 /* ---- whole-solve boundary ---------------------------------------------------------------------------------
  * Mirrors  solve_mv / solve_sim (key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate,

@@ -15,6 +15,7 @@ RK_ERR_INVALID, RK_ERR_UNSUPPORTED, RK_ERR_HIP, RK_ERR_RCCL, RK_ERR_NOMEM = -1, 
 KALMAN_STANDARD, KALMAN_SQRT = 0, 1
 INTERROGATE_RODEO, INTERROGATE_SCHOBER, INTERROGATE_KRAMER, INTERROGATE_CHKREBTII = 0, 1, 2, 3
 RHS_FITZHUGH_NAGUMO, RHS_LORENZ63, RHS_HIGHER_ORDER, RHS_LINEAR_DENSE = 1, 2, 3, 4
+RHS_USER_BASE = 1000
 FLAG_STORE_PRED = 1
 FLAG_BATCH_MINOR = 2
 MODE_FILTER, MODE_MV, MODE_SIM = 0, 1, 2
@@ -76,6 +77,8 @@ SIGNATURES = {
     "rk_timer_stop": (C.c_int, [_H, C.POINTER(_D)]),
     "rk_profile_enable": (C.c_int, [_H, C.c_int]),
     "rk_profile_last": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_D), C.POINTER(C.c_int)]),
+    "rk_register_rhs_source": (C.c_int, [C.c_char_p, C.c_char_p, _I, _I, C.POINTER(_I)]),
+    "rk_rhs_compile_check": (C.c_int, [_I, _I, _I]),
     "rk_solve_layout": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(_I)]),
     "rk_solve_sizes": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rk_solve_workspace_bytes": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(C.c_size_t)]),

@@ -1,0 +1,120 @@
+// Forward-mode dual numbers for user-supplied right-hand sides: the device counterpart of the
+// jax.jacfwd(ode_fun) call of src/rodeo/interrogate.py:76, restricted to what interrogate_kramer keeps -- the
+// block-diagonal d f_b / d X[b][:] (interrogate.py:78-79).
+//
+// A user ODE written once on a generic scalar type,
+//     struct MyOde {
+//         static constexpr int D = ..., NTHETA = ..., NDEP = 1;
+//         template <class T, int P> __device__ static void rhs(const T (&X)[D][P], double t,
+//                                                              const double (&th)[NTHETA], T (&out)[D]);
+//     };
+// becomes a complete right-hand side (f and fjac) through rk::AutoJac<MyOde>.
+#pragma once
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>
+#endif
+
+namespace rk {
+
+template <int P>
+struct Dual {
+    double v;
+    double d[P];
+    __device__ __forceinline__ Dual() : v(0.0) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) d[i] = 0.0;
+    }
+    __device__ __forceinline__ Dual(double x) : v(x) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) d[i] = 0.0;
+    }
+};
+
+#define RK_DUAL_BIN(OP, VEXPR, DEXPR)                                                                    \
+    template <int P>                                                                                      \
+    __device__ __forceinline__ Dual<P> operator OP(const Dual<P>& a, const Dual<P>& b) {                  \
+        Dual<P> r;                                                                                        \
+        r.v = VEXPR;                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < P; ++i) r.d[i] = DEXPR;                                     \
+        return r;                                                                                         \
+    }                                                                                                     \
+    template <int P>                                                                                      \
+    __device__ __forceinline__ Dual<P> operator OP(const Dual<P>& a, double b) { return a OP Dual<P>(b); } \
+    template <int P>                                                                                      \
+    __device__ __forceinline__ Dual<P> operator OP(double a, const Dual<P>& b) { return Dual<P>(a) OP b; }
+
+RK_DUAL_BIN(+, a.v + b.v, a.d[i] + b.d[i])
+RK_DUAL_BIN(-, a.v - b.v, a.d[i] - b.d[i])
+RK_DUAL_BIN(*, a.v * b.v, fma(a.d[i], b.v, a.v * b.d[i]))
+RK_DUAL_BIN(/, a.v / b.v, (a.d[i] - (a.v / b.v) * b.d[i]) / b.v)
+#undef RK_DUAL_BIN
+
+template <int P>
+__device__ __forceinline__ Dual<P> operator-(const Dual<P>& a) {
+    Dual<P> r;
+    r.v = -a.v;
+#pragma unroll
+    for (int i = 0; i < P; ++i) r.d[i] = -a.d[i];
+    return r;
+}
+
+// plain-double overloads so that generic code inside namespace rk can call sin(x), exp(x), ... on either scalar type
+__device__ __forceinline__ double sin(double x) { return ::sin(x); }
+__device__ __forceinline__ double cos(double x) { return ::cos(x); }
+__device__ __forceinline__ double exp(double x) { return ::exp(x); }
+__device__ __forceinline__ double log(double x) { return ::log(x); }
+__device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+__device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
+
+#define RK_DUAL_FUN(NAME, VEXPR, DFAC)                                      \
+    template <int P>                                                         \
+    __device__ __forceinline__ Dual<P> NAME(const Dual<P>& a) {              \
+        Dual<P> r;                                                           \
+        r.v = VEXPR;                                                         \
+        const double fac = DFAC;                                             \
+        _Pragma("unroll") for (int i = 0; i < P; ++i) r.d[i] = fac * a.d[i]; \
+        return r;                                                            \
+    }
+RK_DUAL_FUN(sin, ::sin(a.v), ::cos(a.v))
+RK_DUAL_FUN(cos, ::cos(a.v), -::sin(a.v))
+RK_DUAL_FUN(exp, ::exp(a.v), r.v)
+RK_DUAL_FUN(log, ::log(a.v), 1.0 / a.v)
+RK_DUAL_FUN(sqrt, ::sqrt(a.v), 0.5 / r.v)
+RK_DUAL_FUN(tanh, ::tanh(a.v), 1.0 - r.v * r.v)
+#undef RK_DUAL_FUN
+
+// Adapter: a scalar-generic `rhs` -> the (f, fjac) interface of csrc/rhs.hpp
+template <class U>
+struct AutoJac {
+    static constexpr int D = U::D;
+    static constexpr int NTHETA = U::NTHETA;
+    static constexpr int NDEP = U::NDEP;
+    static constexpr bool HAS_TILE_FORM = false;
+    template <int P>
+    __device__ __forceinline__ static void f(const double (&X)[D][P], double t, const double (&th)[NTHETA],
+                                             double (&out)[D]) {
+        U::template rhs<double, P>(X, t, th, out);
+    }
+    template <int P>
+    __device__ __forceinline__ static void fjac(const double (&X)[D][P], double t, const double (&th)[NTHETA],
+                                                double (&out)[D], double (&J)[D][P]) {
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            // seed the P directions of block b; the other blocks are constants (their partials are dropped)
+            Dual<P> Xd[D][P], od[D];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb)
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    Xd[bb][j] = Dual<P>(X[bb][j]);
+                    if (bb == b) Xd[bb][j].d[j] = 1.0;
+                }
+            U::template rhs<Dual<P>, P>(Xd, t, th, od);
+            out[b] = od[b].v;
+#pragma unroll
+            for (int j = 0; j < P; ++j) J[b][j] = od[b].d[j];
+        }
+    }
+};
+
+}  // namespace rk

@@ -3,7 +3,9 @@
 // go to scratch).  Operation order follows the reference's expressions (src/rodeo/kalmantv/standard.py) so that the
 // rounding pattern stays as close to the JAX path as a different BLAS allows.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 namespace rk {
 

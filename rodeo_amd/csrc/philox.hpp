@@ -9,7 +9,9 @@
 //   counter = (global trajectory index, step, block | purpose << 16, chunk)
 //   one call -> 4 x u32 -> 2 uniforms in (0,1) -> 2 normals (cos, sin)
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace rk {

@@ -8,7 +8,9 @@
 //                                                                  interrogate.py:70)
 // NumPy mirrors used by the tests: oracle/odes.py.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 namespace rk {
 

@@ -1,0 +1,168 @@
+// User-supplied ODE right-hand sides: hiprtc builds of the forward / interrogation kernels.
+//
+// rodeo's `ode_fun` is an arbitrary Python callable evaluated inside the scan (src/rodeo/solve.py:70-78) and
+// differentiated by jax.jacfwd (src/rodeo/interrogate.py:76).  Here the time loop lives in one GPU kernel, so a new ODE
+// arrives as HIP source for a small struct (the interface of csrc/rhs.hpp, or a scalar-generic `rhs` wrapped by
+// rk::AutoJac of csrc/dual.hpp for the Jacobian) and the kernel templates of solve_small_kernels.hpp are
+// instantiated for it at run time, once per (n_bstate, interrogation) actually used.
+#include <hip/hiprtc.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "common.hpp"
+#include "solve_args.hpp"
+#include "build/embedded_sources.inc"
+
+namespace rk {
+
+struct UserRhs {
+    std::string type_name;      // C++ type inside namespace rk, e.g. "MyOde" or "AutoJac<MyOde>"
+    std::string source;
+    int n_block, n_theta;
+};
+
+static std::mutex g_mu;
+static std::vector<UserRhs> g_rhs;                                   // id = RK_RHS_USER_BASE + index
+struct JitEntry { hipModule_t mod; hipFunction_t fn; };
+static std::map<std::tuple<int, int, int, int, int>, JitEntry> g_cache;   // (device, rhs, P, itg, kind)
+
+static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
+    char buf[512];
+    (void)u;   // the user's type is aliased to rk::UserRhsT inside the translation unit (it may be a template-id)
+    if (kind == 2) snprintf(buf, sizeof buf, "rk::interrogate_kernel<rk::UserRhsT, %d, %d>", P, itg);
+    else snprintf(buf, sizeof buf, "rk::fwd_kernel<rk::UserRhsT, %d, %d, %s>", P, itg, kind == 1 ? "true" : "false");
+    return buf;
+}
+
+// compile one instantiation; returns code object in `code` and the mangled name in `lowered`
+static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<char>& code, std::string& lowered) {
+    const std::string src = std::string("#include \"solve_small_kernels.hpp\"\n#include \"dual.hpp\"\nnamespace rk {\n") +
+                            u.source + "\nusing UserRhsT = " + u.type_name + ";\n}  // namespace rk\n";
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "rk_user_rhs.hip", kJitNumHeaders, kJitHeaderSources, kJitHeaderNames) !=
+        HIPRTC_SUCCESS) {
+        set_error("hiprtcCreateProgram failed");
+        return RK_ERR_HIP;
+    }
+    const std::string expr = kernel_expr(u, P, itg, kind);
+    hiprtcAddNameExpression(prog, expr.c_str());
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t ls = 0;
+        hiprtcGetProgramLogSize(prog, &ls);
+        std::string log(ls, '\0');
+        if (ls) hiprtcGetProgramLog(prog, &log[0]);
+        if (log.size() > 800) log.resize(800);
+        set_error("hiprtc could not compile the user right-hand side '%s': %s", u.type_name.c_str(), log.c_str());
+        hiprtcDestroyProgram(&prog);
+        return RK_ERR_INVALID;
+    }
+    const char* low = nullptr;
+    if (hiprtcGetLoweredName(prog, expr.c_str(), &low) != HIPRTC_SUCCESS || !low) {
+        set_error("hiprtcGetLoweredName failed for %s", expr.c_str());
+        hiprtcDestroyProgram(&prog);
+        return RK_ERR_HIP;
+    }
+    lowered = low;
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    code.resize(cs);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return RK_OK;
+}
+
+static int jit_get(rk_handle h, int rhs_id, int P, int itg, int kind, hipFunction_t* fn) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int idx = rhs_id - RK_RHS_USER_BASE;
+    RK_REQUIRE(idx >= 0 && idx < (int)g_rhs.size(), RK_ERR_INVALID, "unknown user rhs_id %d", rhs_id);
+    const auto key = std::make_tuple(h->device, rhs_id, P, itg, kind);
+    auto it = g_cache.find(key);
+    if (it == g_cache.end()) {
+        std::vector<char> code;
+        std::string lowered;
+        int rc = jit_compile(g_rhs[idx], P, itg, kind, code, lowered);
+        if (rc) return rc;
+        JitEntry e;
+        RK_HIP(hipModuleLoadData(&e.mod, code.data()));
+        RK_HIP(hipModuleGetFunction(&e.fn, e.mod, lowered.c_str()));
+        it = g_cache.emplace(key, e).first;
+    }
+    *fn = it->second.fn;
+    return RK_OK;
+}
+
+bool is_user_rhs(int rhs_id) { return rhs_id >= RK_RHS_USER_BASE; }
+
+int user_rhs_check(const rk_solve_cfg* c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int idx = c->rhs_id - RK_RHS_USER_BASE;
+    RK_REQUIRE(idx >= 0 && idx < (int)g_rhs.size(), RK_ERR_INVALID, "unknown user rhs_id %d", c->rhs_id);
+    RK_REQUIRE(c->n_block == g_rhs[idx].n_block && c->n_bmeas == 1, RK_ERR_UNSUPPORTED,
+               "user rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, g_rhs[idx].n_block, c->n_block, c->n_bmeas);
+    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 5, RK_ERR_UNSUPPORTED, "small-block path supports n_bstate in [2, 5], got %d",
+               c->n_bstate);
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED,
+               "user right-hand sides are available with kalman_type=standard only");
+    return RK_OK;
+}
+
+int user_forward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
+    int rc = user_rhs_check(c);
+    if (rc) return rc;
+    hipFunction_t fn;
+    rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, (c->flags & RK_FLAG_STORE_PRED) ? 1 : 0, &fn);
+    if (rc) return rc;
+    SolveArgs args = a;
+    void* params[] = {&args};
+    LaunchTimer t(h, "fwd_kernel<user>");
+    RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B, 64), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));
+    t.stop();
+    return RK_OK;
+}
+
+int user_interrogate(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double t, int step, const double* mp,
+                     const double* vp, double* wm, double* mm_, double* vm) {
+    int rc = user_rhs_check(c);
+    if (rc) return rc;
+    hipFunction_t fn;
+    rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, 2, &fn);
+    if (rc) return rc;
+    SolveArgs args = a;
+    void* params[] = {&args, &t, &step, &mp, &vp, &wm, &mm_, &vm};
+    RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B, 64), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));
+    return RK_OK;
+}
+
+}  // namespace rk
+
+using namespace rk;
+
+extern "C" {
+
+int rk_register_rhs_source(const char* type_name, const char* source, int32_t n_block, int32_t n_theta, int32_t* rhs_id) {
+    RK_REQUIRE(type_name && source && rhs_id, RK_ERR_INVALID, "rk_register_rhs_source: null argument");
+    RK_REQUIRE(n_block >= 1 && n_block <= 8 && n_theta >= 0, RK_ERR_INVALID, "rk_register_rhs_source: bad n_block / n_theta");
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_rhs.push_back(UserRhs{type_name, source, n_block, n_theta});
+    *rhs_id = RK_RHS_USER_BASE + (int)g_rhs.size() - 1;
+    return RK_OK;
+}
+
+int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate) {
+    UserRhs u;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        const int idx = rhs_id - RK_RHS_USER_BASE;
+        RK_REQUIRE(idx >= 0 && idx < (int)g_rhs.size(), RK_ERR_INVALID, "unknown user rhs_id %d", rhs_id);
+        u = g_rhs[idx];
+    }
+    std::vector<char> code;
+    std::string lowered;
+    return jit_compile(u, n_bstate, interrogate, 0, code, lowered);
+}
+
+}  // extern "C"

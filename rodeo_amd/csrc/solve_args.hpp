@@ -1,6 +1,8 @@
 // Kernel argument block shared by the fused solver kernels (batch-minor inputs of include/rodeo_kalman.h).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace rk {

@@ -11,152 +11,9 @@
 #include "philox.hpp"
 #include "rhs.hpp"
 #include "solve_args.hpp"
+#include "solve_small_kernels.hpp"
 
 namespace rk {
-
-// ---- interrogation of one trajectory (all blocks): src/rodeo/interrogate.py -----------------------------------
-// Produces W_meas = ode_weight + wgt_meas (solve.py:79), mean_meas and var_meas (n_bmeas = 1 -> scalars per block).
-template <class RHS, int P, int ITG>
-__device__ __forceinline__ void interrogate_traj(const double (&W)[RHS::D][P], const double (&th)[RHS::NTHETA],
-                                                 double t, const double (&mup)[RHS::D][P],
-                                                 const double (&Sp)[RHS::D][P][P], uint64_t seed, uint32_t traj,
-                                                 uint32_t step, double (&wgt)[RHS::D][P], double (&a)[RHS::D],
-                                                 double (&V)[RHS::D]) {
-    constexpr int D = RHS::D;
-    double f[D];
-    if constexpr (ITG == RK_INTERROGATE_KRAMER) {
-        // interrogate.py:75-84: wgt_meas = -J ; mean_meas = -f + J mu- ; var_meas = 0
-        double J[D][P];
-        RHS::template fjac<P>(mup, t, th, f, J);
-#pragma unroll
-        for (int blk = 0; blk < D; ++blk) {
-            a[blk] = -f[blk] + dot<P>(J[blk], mup[blk]);
-            V[blk] = 0.0;
-#pragma unroll
-            for (int j = 0; j < P; ++j) wgt[blk][j] = -J[blk][j];
-        }
-    } else {
-        if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
-            // interrogate.py:22-34,46: x_b ~ N(mu-_b, Sigma-_b) ; mean_meas = -f(x) ; var_meas = W Sigma- W^T
-            double xs[D][P];
-#pragma unroll
-            for (int blk = 0; blk < D; ++blk) {
-                double z[P];
-                normals<P>(seed, traj, step, (uint32_t)blk, PURPOSE_INTERROGATE, z);
-                mvn_draw<P>(mup[blk], Sp[blk], z, xs[blk]);
-            }
-            RHS::template f<P>(xs, t, th, f);
-        } else {
-            // interrogate.py:61 / :114: mean_meas = -f(mu-)
-            RHS::template f<P>(mup, t, th, f);
-        }
-#pragma unroll
-        for (int blk = 0; blk < D; ++blk) {
-            a[blk] = -f[blk];
-#pragma unroll
-            for (int j = 0; j < P; ++j) wgt[blk][j] = 0.0;
-            if constexpr (ITG == RK_INTERROGATE_SCHOBER) {
-                V[blk] = 0.0;                                     // interrogate.py:60
-            } else {
-                double WS[P];                                     // interrogate.py:110-113 / :26-29
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    double s = W[blk][0] * Sp[blk][0][j];
-#pragma unroll
-                    for (int i = 1; i < P; ++i) s = fma(W[blk][i], Sp[blk][i][j], s);
-                    WS[j] = s;
-                }
-                V[blk] = dot<P>(WS, W[blk]);
-            }
-        }
-    }
-}
-
-// ---- forward pass: one lane per trajectory -----------------------------------------------------------------------
-template <class RHS, int P, int ITG, bool STORE_PRED>
-__global__ void __launch_bounds__(64) fwd_kernel(SolveArgs a) {
-    constexpr int D = RHS::D;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
-    const size_t B = (size_t)a.B;
-
-    double Q[D][P][P], R[D][P][P], W[D][P], th[RHS::NTHETA];
-#pragma unroll
-    for (int blk = 0; blk < D; ++blk) {
-        load_block_consts<P>(a, blk, b, Q[blk], R[blk]);
-#pragma unroll
-        for (int j = 0; j < P; ++j) W[blk][j] = ld(a.W, (size_t)blk * P + j, a.W_b, a.B, b);
-    }
-#pragma unroll
-    for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
-
-    double mu[D][P], S[D][P][P];
-#pragma unroll
-    for (int blk = 0; blk < D; ++blk)
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            mu[blk][i] = ld(a.x0, (size_t)blk * P + i, a.x0_b, a.B, b);
-#pragma unroll
-            for (int j = 0; j < P; ++j) S[blk][i][j] = 0.0;
-        }
-
-    // time index 0: (ode_init, 0) for filt and pred (solve.py:114-121)
-#pragma unroll
-    for (int blk = 0; blk < D; ++blk)
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const size_t em = (size_t)blk * P + i;
-            a.mean[em * B + b] = mu[blk][i];
-            if (STORE_PRED) a.mean_pred[em * B + b] = mu[blk][i];
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                a.var[(em * P + j) * B + b] = 0.0;
-                if (STORE_PRED) a.var_pred[(em * P + j) * B + b] = 0.0;
-            }
-        }
-
-    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
-    const size_t mstride = (size_t)D * P * B, vstride = (size_t)D * P * P * B;
-    for (int n = 0; n < a.N; ++n) {
-        double mup[D][P], Sp[D][P][P];
-#pragma unroll
-        for (int blk = 0; blk < D; ++blk) predict_block<P>(Q[blk], R[blk], mu[blk], S[blk], mup[blk], Sp[blk]);
-
-        const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
-        double wgt[D][P], am[D], V[D];
-        interrogate_traj<RHS, P, ITG>(W, th, t, mup, Sp, a.seed, traj, (uint32_t)n, wgt, am, V);
-
-        double* mo = a.mean + (size_t)(n + 1) * mstride + b;
-        double* vo = a.var + (size_t)(n + 1) * vstride + b;
-#pragma unroll
-        for (int blk = 0; blk < D; ++blk) {
-            double Wm[P];
-#pragma unroll
-            for (int j = 0; j < P; ++j) Wm[j] = W[blk][j] + wgt[blk][j];                      // solve.py:79
-            update_block_m1<P>(Wm, am[blk], V[blk], mup[blk], Sp[blk], mu[blk], S[blk]);
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const size_t em = (size_t)blk * P + i;
-                mo[em * B] = mu[blk][i];
-#pragma unroll
-                for (int j = 0; j < P; ++j) vo[(em * P + j) * B] = S[blk][i][j];
-            }
-        }
-        if (STORE_PRED) {
-            double* mpo = a.mean_pred + (size_t)(n + 1) * mstride + b;
-            double* vpo = a.var_pred + (size_t)(n + 1) * vstride + b;
-#pragma unroll
-            for (int blk = 0; blk < D; ++blk)
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    const size_t em = (size_t)blk * P + i;
-                    mpo[em * B] = mup[blk][i];
-#pragma unroll
-                    for (int j = 0; j < P; ++j) vpo[(em * P + j) * B] = Sp[blk][i][j];
-                }
-        }
-    }
-}
 
 // ---- backward passes: one lane per (block, trajectory) -----------------------------------------------------------
 template <int P>
@@ -263,40 +120,6 @@ __global__ void __launch_bounds__(64) bwd_sim_kernel(SolveArgs a) {
     store_x(0, x0);
 }
 
-// ---- one interrogation for a batch (per-step boundary) ------------------------------------------------------------
-template <class RHS, int P, int ITG>
-__global__ void __launch_bounds__(64) interrogate_kernel(SolveArgs a, double t, int step, const double* mean_pred,
-                                                         const double* var_pred, double* wgt_meas,
-                                                         double* mean_meas, double* var_meas) {
-    constexpr int D = RHS::D;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
-    const size_t B = (size_t)a.B;
-    double W[D][P], th[RHS::NTHETA], mup[D][P], Sp[D][P][P];
-#pragma unroll
-    for (int blk = 0; blk < D; ++blk)
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const size_t em = (size_t)blk * P + i;
-            W[blk][i] = ld(a.W, em, a.W_b, a.B, b);
-            mup[blk][i] = mean_pred[em * B + b];
-#pragma unroll
-            for (int j = 0; j < P; ++j) Sp[blk][i][j] = var_pred[(em * P + j) * B + b];
-        }
-#pragma unroll
-    for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
-    double wgt[D][P], am[D], V[D];
-    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
-    interrogate_traj<RHS, P, ITG>(W, th, t, mup, Sp, a.seed, traj, (uint32_t)step, wgt, am, V);
-#pragma unroll
-    for (int blk = 0; blk < D; ++blk) {
-        mean_meas[(size_t)blk * B + b] = am[blk];
-        var_meas[(size_t)blk * B + b] = V[blk];
-#pragma unroll
-        for (int j = 0; j < P; ++j) wgt_meas[((size_t)blk * P + j) * B + b] = wgt[blk][j];
-    }
-}
-
 // ---- Gaussian observation log-posterior reduction (docs/examples/parameter.md:188-210) ---------------------------
 __global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile, int tile_off, const double* x, const double* obs, const int32_t* obs_ind,
                                      int n_obs, double noise_sd, const double* upars, int n_prior, double prior_sd,
@@ -396,7 +219,11 @@ static int launch_fwd_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a
     return RK_ERR_UNSUPPORTED;
 }
 
+int user_forward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a);
+bool is_user_rhs(int rhs_id);
+
 int small_forward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
+    if (is_user_rhs(c->rhs_id)) return user_forward(h, c, a);
     switch (c->rhs_id) {
         case RK_RHS_FITZHUGH_NAGUMO: return launch_fwd_rhs<FitzHughNagumo>(h, c, a);
         case RK_RHS_LORENZ63: return launch_fwd_rhs<Lorenz63>(h, c, a);
@@ -461,6 +288,12 @@ bool dense_supported(const rk_solve_cfg* c, int mode);
 int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode);
 int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, int mode);
 size_t dense_ws_doubles(int p, int m);
+
+// user-supplied right-hand sides (rhs_jit.hip)
+bool is_user_rhs(int rhs_id);
+int user_forward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a);
+int user_interrogate(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double t, int step, const double* mp,
+                     const double* vp, double* wm, double* mm_, double* vm);
 
 // fused square-root solver (solve_sqrt.hip)
 int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode);
@@ -547,7 +380,11 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     h->event_used = 0;
     SolveArgs a;
     make_args(c, in, out, a);
-    if (c->kalman_type == RK_KALMAN_SQRT) return sqrt_solve(h, c, a, mode);
+    if (c->kalman_type == RK_KALMAN_SQRT) {
+        RK_REQUIRE(!is_user_rhs(c->rhs_id), RK_ERR_UNSUPPORTED,
+                   "user right-hand sides are available with kalman_type=standard only");
+        return sqrt_solve(h, c, a, mode);
+    }
     if (tile4) return tile4_solve(h, c, a, out->var_state, mode);
     if (tile) return tile3_solve(h, c, a, out->var_state, mode);
     rc = small_forward(h, c, a);
@@ -578,6 +415,8 @@ int rk_interrogate_batched(rk_handle h, const rk_solve_cfg* c, const rk_solve_in
     RK_HIP(hipSetDevice(h->device));
     SolveArgs a;
     make_args(c, in, nullptr, a);
+    if (is_user_rhs(c->rhs_id))
+        return user_interrogate(h, c, a, t, step, mean_state_pred, var_state_pred, wgt_meas, mean_meas, var_meas);
     switch (c->rhs_id) {
         case RK_RHS_FITZHUGH_NAGUMO:
             return launch_itg_rhs<FitzHughNagumo>(h, c, a, t, step, mean_state_pred, var_state_pred, wgt_meas, mean_meas, var_meas);

@@ -111,3 +111,33 @@ def linear_dense(n_vars, n_deriv):
 
     ode.pack_params = pack
     return ode
+
+
+def from_source(type_name, source, n_block, param_spec=(), host_fun=None, name=None):
+    """
+    Register an ODE that is not built in, from HIP source (compiled with hiprtc on first use).
+
+    ``source`` defines, inside ``namespace rk``, either a struct with the full interface of
+    rodeo_amd/csrc/rhs.hpp (``D``, ``NTHETA``, ``NDEP``, ``f<P>``, ``fjac<P>``) -- then ``type_name`` is its name -- or a
+    struct with a scalar-generic ``rhs<T, P>`` -- then pass ``type_name="AutoJac<Name>"`` and the block-diagonal
+    Jacobian that ``interrogate_kramer`` needs (``jax.jacfwd`` in src/rodeo/interrogate.py:76-79) comes from
+    forward-mode dual numbers (rodeo_amd/csrc/dual.hpp).  ``param_spec`` = ((kwarg name, size), ...) fixes how
+    ``**params`` are packed into ``th[]``; ``host_fun(X, t, **params)`` is the NumPy twin used only for host-side input
+    preparation (``first_order_pad``).  n_bmeas = 1, kalman_type "standard".
+    """
+    import ctypes as C
+    lib = _lib.load()
+    rid = C.c_int32(0)
+    n_theta = sum(s for _, s in param_spec)
+    _lib.check(lib.rk_register_rhs_source(type_name.encode(), source.encode(), int(n_block), max(int(n_theta), 0),
+                                          C.byref(rid)))
+
+    def _no_host(X, t, **params):
+        raise TypeError(f"ODE '{name or type_name}' was registered without a host_fun; it cannot be evaluated on the host")
+
+    return DeviceODE(name or type_name, rid.value, int(n_block), 1, param_spec, host_fun or _no_host)
+
+
+def compile_check(ode, n_bstate, interrogate_id=_lib.INTERROGATE_KRAMER):
+    """Compile the kernels for a ``from_source`` ODE without a GPU; raises RodeoKalmanError with the compiler log."""
+    _lib.check(_lib.load().rk_rhs_compile_check(int(ode.rhs_id), int(n_bstate), int(interrogate_id)))
