@@ -48,6 +48,7 @@ __device__ __forceinline__ double pair_other(double x) {
 
 // broadcast column 3 of every (r, g) quad to its four lanes
 __device__ __forceinline__ double quad_bcast3(double x) { return dpp64<0xFF>(x); }
+__device__ __forceinline__ double quad_bcast0(double x) { return dpp64<0x00>(x); }
 // value held by the same (r, c) lane of tile g-1 / g+1 (cyclic within the 16-lane row)
 __device__ __forceinline__ double from_prev_tile(double x) { return dpp64<0x124>(x); }   // row_ror:4
 __device__ __forceinline__ double from_next_tile(double x) { return dpp64<0x12C>(x); }   // row_ror:12

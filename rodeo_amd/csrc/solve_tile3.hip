@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "kalman_small.hpp"
 #include "mfma_tile.hpp"
+#include "philox.hpp"
 #include "rhs.hpp"
 #include "solve_args.hpp"
 
@@ -75,6 +76,8 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
     double tk[6] = {0, 0, 0, 0, 0, 0};
     if constexpr (RHS::HAS_TILE_FORM && D == 2) RHS::tile_consts(blk, th, tk);
+    __shared__ double zbuf[4 * 16];                    // chkrebtii: z_0 of the next 16 steps for each of the 4 tiles
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
 
     // M_0 = [0 | ode_init ; 0 1]   (solve.py:53-54)
     double M = r < 3 ? (c == 3 ? ld(a.x0, (size_t)blk * P + r, a.x0_b, a.B, b) : 0.0) : (c == 3 ? 1.0 : 0.0);
@@ -92,11 +95,24 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         // (a 4x4x4 fp64 MFMA blocks this wave's issue for ~17 cycles = 4 fp64 VALU ops, and nothing overlaps it --
         //  profiles/r01_probe3_mfma_valu_serialize.log -- so the step is written with the fewest MFMAs: seven)
         const double U = MF(M, Qt, 0.0);
-        const double B0 = MF(Y0, M, 0.0);
+        double v_own;                                  // the point the ODE is evaluated at: X[b][0] of this tile's block
+        if constexpr (ITG != RK_INTERROGATE_CHKREBTII) v_own = quad_bcast3(MF(Y0, M, 0.0));   // mu-_0 in all 16 lanes
         const double Mp = MF(U, Qt, Rt);
         const double MpT = MF(Qt, U, RtT);             // exact transpose of M-: Q~ M^T Q~^T + R~^T
-        // ---- interrogation (interrogate.py): f and the block-diagonal Jacobian at mu- ----
-        const double v_own = quad_bcast3(B0);          // mu-_0 of this tile's block, in all 16 lanes
+        if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
+            // interrogate.py:22-34: x ~ N(mu-, Sigma-) with the lower factor; only x_0 = mu-_0 + sqrt(Sigma-_00) z_0
+            // reaches f (RHS::NDEP == 1).  The 16 lanes of a tile draw z_0 for 16 consecutive steps at once.
+            if ((n & 15) == 0) {
+                double z0, z1;
+                normal_pair(a.seed, traj, (uint32_t)(n + r * 4 + c), (uint32_t)blk, PURPOSE_INTERROGATE, 0u, z0, z1);
+                zbuf[tc.g * 16 + r * 4 + c] = z0;
+            }
+            const double zn = zbuf[tc.g * 16 + (n & 15)];
+            const double R0 = MF(E0, Mp, 0.0);         // row 0 of M- in every row: [Sigma-_00 .. | mu-_0]
+            const double s00 = quad_bcast0(R0);
+            v_own = fma(sqrt(s00 > 0.0 ? s00 : 0.0), zn, quad_bcast3(R0));
+        }
+        // ---- interrogation (interrogate.py): f and the block-diagonal Jacobian at v_own ----
         const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
         double fb, J0;
         if constexpr (RHS::HAS_TILE_FORM && D == 2) {
@@ -134,7 +150,8 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         const double WS = MF(Xw, Mp, 0.0);                          // [W~ Sigma- | W~ mu- + a]   (column form)
         const double Z0 = MF(MpT, Xw * m3, 0.0);                    // Sigma- W~^T (standard.py:97; row form, 0 in row 3)
         double S = MF(Z0, Xw, 0.0);
-        if constexpr (ITG == RK_INTERROGATE_RODEO) S = S + S;       // var_meas = W Sigma- W^T (interrogate.py:110-113)
+        if constexpr (ITG == RK_INTERROGATE_RODEO || ITG == RK_INTERROGATE_CHKREBTII)
+            S = S + S;                                              // var_meas = W Sigma- W^T (interrogate.py:110-113, 26-29)
         const double K = Z0 * fast_rcp(S);
         M = fma(-K, WS, Mp);
         out += tstride;
@@ -321,6 +338,166 @@ __global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* 
     }
 }
 
+// ---- backward sampler (solve.py:162-204): x_n = mu_f + G (x_{n+1} - mu-) + L~ z_n --------------------------------
+// Everything but the chain in x is carry-independent, so the producers (same two-phase scheme as above) evaluate per
+// (step, tile): G, mu-, and mu_f + L~ z with L~ = psd_factor(Sigma_f - G T^T) (standard.py:248-254, the draw of
+// solve.py:179) and the Philox normals; the consumer's dependent chain is ONE MFMA per step:
+//     x = MF(G~^T, x - mu-, mu_f + L~ z)        (x, mu-, ... in row form: lane (r, g, c) holds component r)
+// The terminal draw x_N ~ N(filt[N]) (solve.py:182-186) is the same step with G = 0.  Hand-off item: 256 B.
+constexpr int SIM_ITEM = 256;                   // [G~^T tile 128 B | mu- 32 B | mu_f + L z 32 B | pad]
+constexpr int SIM_BUF = CHUNK * 4 * SIM_ITEM;   // 16 KiB
+
+__device__ __forceinline__ int sim_tile_byte(int s, int g, int idx) {
+    const int item = s * 4 + g;
+    return item * SIM_ITEM + ((idx ^ (item & 15)) << 3);
+}
+__device__ __forceinline__ int sim_vec_byte(int s, int g, int which, int rr) {
+    const int item = s * 4 + g;
+    return item * SIM_ITEM + 128 + which * 32 + ((rr ^ (item & 3)) << 3);
+}
+
+__global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D) {
+    constexpr int P = 3;
+    __shared__ __attribute__((aligned(16))) char lds_all[2 * 2 * SIM_BUF];
+    const int wave_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_tiles = a.B * D;
+    const size_t tstride = (size_t)n_tiles * TILE_DOUBLES;
+    const int n_chunks = (a.N + CHUNK - 1) / CHUNK;                // steps n = N .. 1 (n = N is the terminal draw)
+    for (int i = threadIdx.x; i < 2 * 2 * SIM_BUF / 8; i += 512) ((double*)lds_all)[i] = 0.0;
+    __syncthreads();
+    if (wave_id == 4 || wave_id == 5) return;
+    const int grp = wave_id & 1;
+    const int role = wave_id < 2 ? 0 : (wave_id < 4 ? 1 : 2);
+    const int tw = blockIdx.x * 2 + grp;
+    char* const lds_raw = lds_all + grp * 2 * SIM_BUF;
+    double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)tw * 64;
+
+    if (role >= 1) {
+        // ---------------- producers ----------------
+        const int p = role - 1;
+        const int s = lane >> 2, g = lane & 3;
+        int tau = tw * 4 + g;
+        if (tau >= n_tiles) tau = n_tiles - 1;
+        const int b = tau / D, blk = tau - b * D;
+        const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+        double Q[P][P], R[P][P];
+        load_block_consts<P>(a, blk, b, Q, R);
+        const double* tin = tiles + (size_t)tau * TILE_DOUBLES;
+        int woff[9], voff[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) woff[i * 3 + j] = sim_tile_byte(s, g, i * 4 + j);
+            voff[i] = sim_vec_byte(s, g, 0, i);
+        }
+        double bufE[TILE_DOUBLES], bufO[TILE_DOUBLES];
+        auto fetch = [&](int ch, double (&dst)[TILE_DOUBLES]) {
+            int n = a.N - ch * CHUNK - s;
+            n = n < 1 ? 1 : n;
+            const double* in = tin + (size_t)n * tstride;
+#pragma unroll
+            for (int i = 0; i < TILE_DOUBLES; ++i) dst[i] = in[i];
+        };
+        if (p < n_chunks) fetch(p, bufE);
+        if (p + 2 < n_chunks) fetch(p + 2, bufO);
+        double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P], z[P];
+        auto phaseA = [&](int chA, double (&buf)[TILE_DOUBLES]) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+#pragma unroll
+                for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
+                mf[i] = buf[i * 4 + 3];
+            }
+            if (chA + 4 < n_chunks) fetch(chA + 4, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            const int n = a.N - chA * CHUNK - s;
+            normals<P>(a.seed, traj, (uint32_t)(n < 1 ? 1 : n), (uint32_t)blk, PURPOSE_SMOOTH, z);
+            predict_block<P>(Q, R, mf, Sf, mp, Sp);
+            mm_nt<P, P, P>(Sf, Q, T);
+        };
+        for (int t = -2; t < n_chunks; ++t) {
+            const int chA = t + 2, chB = t + 1;
+            if ((chA & 1) == p) {
+                if (chA < n_chunks) {
+                    if ((chA >> 1) & 1) phaseA(chA, bufO); else phaseA(chA, bufE);
+                }
+            } else if (chB >= 0 && chB < n_chunks) {
+                const int n = a.N - chB * CHUNK - s;
+                double A[P][P], X[P][P], GT[P][P], Ssim[P][P], L[P][P], G[P][P];
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
+                lu_solve<P, P>(A, X);                                 // X = G^T   (standard.py:176)
+                const bool term = n == a.N;                           // terminal draw: G = 0, var = filt[N]
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) G[i][j] = term ? 0.0 : X[j][i];
+                mm_nt<P, P, P>(G, T, GT);
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) Ssim[i][j] = Sf[i][j] - GT[i][j];   // standard.py:253-254
+                psd_factor<P>(Ssim, L);
+                if (n >= 1) {
+                    char* o = lds_raw + (chB & 1) * SIM_BUF;
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+                        double w = mf[i];
+#pragma unroll
+                        for (int k = 0; k <= i; ++k) w = fma(L[i][k], z[k], w);
+#pragma unroll
+                        for (int j = 0; j < P; ++j) *(double*)(o + woff[i * 3 + j]) = G[j][i];      // G~^T
+                        *(double*)(o + voff[i]) = term ? 0.0 : mp[i];
+                        *(double*)(o + voff[i] + 32) = w;                                          // mu_f + L z
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---------------- consumer ----------------
+        const TileCoord tc = tile_coord<1>(tw, lane, n_tiles);
+        const int r = tc.r, g = tc.g, c = tc.c, idx = r * 4 + c;
+        const int b = tc.tau / D, blk = tc.tau - b * D;
+        const bool st = tc.valid && r < 3 && c == 0;
+        const size_t xstride = (size_t)D * P * a.B;
+        double* bx = st ? a.x + ((size_t)blk * P + r) * a.B + b : dump + lane;
+        const size_t sx = st ? xstride : 0;
+        int roff[4], rvec[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            roff[k] = sim_tile_byte(k, g, idx) - k * 4 * SIM_ITEM;
+            rvec[k] = sim_vec_byte(k, g, 0, r) - k * 4 * SIM_ITEM;
+        }
+        double x = 0.0;
+        __syncthreads();
+        __syncthreads();
+        for (int t = 0; t < n_chunks; ++t) {
+            const char* in = lds_raw + (t & 1) * SIM_BUF;
+            const int n_hi = a.N - t * CHUNK;
+            const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CHUNK ? CHUNK : n_hi);
+            double* o = bx + (size_t)n_hi * sx;
+            auto step = [&](const char* q, const char* qv) {
+                const double Gt = *(const double*)(q), mp = *(const double*)(qv), mfw = *(const double*)(qv + 32);
+                x = MF(Gt, x - mp, mfw);
+                o[0] = x;
+                o -= sx;
+            };
+            if (cnt == CHUNK) {
+#pragma unroll
+                for (int s = 0; s < CHUNK; ++s) step(in + roff[s & 3] + s * 4 * SIM_ITEM, in + rvec[s & 3] + s * 4 * SIM_ITEM);
+            } else {
+                for (int s = 0; s < cnt; ++s) step(in + sim_tile_byte(s, g, idx), in + sim_vec_byte(s, g, 0, r));
+            }
+            __syncthreads();
+        }
+        // x[0] = ode_init exactly (solve.py:196-204): the mean column of tile time 0
+        if (st) bx[0] = tiles[(size_t)tc.tau * TILE_DOUBLES + r * 4 + 3];
+    }
+}
+
 // ---- dispatch ---------------------------------------------------------------------------------------------------
 template <class RHS>
 static int launch_fwd_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles) {
@@ -333,6 +510,8 @@ static int launch_fwd_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& 
             hipLaunchKernelGGL((fwd_tile3_kernel<RHS, RK_INTERROGATE_SCHOBER>), grid, block, 0, h->stream, a, tiles); break;
         case RK_INTERROGATE_RODEO:
             hipLaunchKernelGGL((fwd_tile3_kernel<RHS, RK_INTERROGATE_RODEO>), grid, block, 0, h->stream, a, tiles); break;
+        case RK_INTERROGATE_CHKREBTII:
+            hipLaunchKernelGGL((fwd_tile3_kernel<RHS, RK_INTERROGATE_CHKREBTII>), grid, block, 0, h->stream, a, tiles); break;
         default:
             set_error("tile path: interrogate id %d not supported", c->interrogate);
             return RK_ERR_UNSUPPORTED;
@@ -344,11 +523,8 @@ static int launch_fwd_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& 
 
 bool tile3_supported(const rk_solve_cfg* c, int mode) {
     if (c->flags & (RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)) return false;
-    if (mode == 2) return false;                                   // solve_sim: batch-minor kernels
     if (c->kalman_type != RK_KALMAN_STANDARD || c->n_bstate != 3 || c->n_bmeas != 1) return false;
-    if (c->interrogate != RK_INTERROGATE_KRAMER && c->interrogate != RK_INTERROGATE_SCHOBER &&
-        c->interrogate != RK_INTERROGATE_RODEO)
-        return false;
+    if (c->interrogate < RK_INTERROGATE_RODEO || c->interrogate > RK_INTERROGATE_CHKREBTII) return false;
     if (c->rhs_id == RK_RHS_FITZHUGH_NAGUMO) return c->n_block == 2;
     if (c->rhs_id == RK_RHS_HIGHER_ORDER) return c->n_block == 1;
     return false;
@@ -358,7 +534,15 @@ int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     int rc;
     if (c->rhs_id == RK_RHS_FITZHUGH_NAGUMO) rc = launch_fwd_tile<FitzHughNagumo>(h, c, a, tiles);
     else rc = launch_fwd_tile<HigherOrder>(h, c, a, tiles);
-    if (rc || mode == 0 || a.N < 2) return rc;
+    if (rc || mode == RK_MODE_FILTER) return rc;
+    if (mode == RK_MODE_SIM) {
+        LaunchTimer t(h, "bwd_sim_tile3_kernel");
+        hipLaunchKernelGGL(bwd_sim_tile3_kernel, dim3(div_up(a.B * a.D, 8)), dim3(512), 0, h->stream, a, tiles, a.D);
+        t.stop();
+        RK_HIP(hipGetLastError());
+        return RK_OK;
+    }
+    if (a.N < 2) return rc;
     LaunchTimer t(h, "bwd_mv_tile3_kernel");
     hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 8)), dim3(512), 0, h->stream, a, tiles, a.D, (c->flags >> 16) & 7);
     t.stop();
