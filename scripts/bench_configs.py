@@ -52,10 +52,14 @@ def c4(args):
         return gauss_obs_logpost(plan, Y, ind, np.sqrt(0.005), upars=upars, n_prior=5)
     ms = timeit(run, plan.dev, 5)
     a = (2 * 2 * 3 * 4 + 2 * 3) * 8
+    plan.dev.profile_enable(True)
+    plan.sim(20242); plan.dev.sync()
+    kern = dict(plan.dev.profile_last())
+    plan.dev.profile_enable(False)
     lp = run().to_host()
     return {"config": "C4 FN pseudo-marginal: 1024 draws/GPU, N=800, solve_sim+chkrebtii+logpost", "ms": ms,
             "traj_steps_per_s": B * N / ms * 1e3, "hbm_frac_solve": a * B * N / (ms * 1e-3) / 8e12,
-            "finite": bool(np.all(np.isfinite(lp)))}
+            "kernels_ms": kern, "finite": bool(np.all(np.isfinite(lp)))}
 
 
 def c5(args):
