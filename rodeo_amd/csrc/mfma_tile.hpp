@@ -53,4 +53,21 @@ __device__ __forceinline__ double quad_bcast0(double x) { return dpp64<0x00>(x);
 __device__ __forceinline__ double from_prev_tile(double x) { return dpp64<0x124>(x); }   // row_ror:4
 __device__ __forceinline__ double from_next_tile(double x) { return dpp64<0x12C>(x); }   // row_ror:12
 
+// ---- LDS hand-off swizzles of the backward kernels (producer lanes: one per item; consumer lanes: tile elements) ----
+// Slot (0..15, in doubles) of element (r, c) inside a 128-byte hand-off tile of item (s, g).  Two access patterns
+// must both be free of LDS bank conflicts (the tiles of all items start at the same bank):
+//   producer stores: 16 consecutive lanes = 16 items (s & 3, g), one element (r, c)   -> slot bijective in (s & 3, g)
+//   consumer loads : 16 / 32 consecutive lanes = one item row s, lanes (g, c), fixed r -> slot bijective in (g, c)
+// slot = 4 (g ^ r) + (c ^ (s & 3)) satisfies both (measured: the earlier idx ^ item swizzle served only the stores
+// and made every consumer load a 4-way conflict, 1300 of 2800 cycles per 16-step tick).
+__device__ __forceinline__ int tile_slot(int s, int g, int idx) {
+    const int r = idx >> 2, c = idx & 3;
+    return 4 * ((g ^ r) & 3) + ((c ^ s) & 3);
+}
+// Same for a 4-vector `which` (0, 1) of item (s, g) inside the item's 128-byte vector area; the consumer's lanes
+// (r, g, c) load element r (c broadcasts).
+__device__ __forceinline__ int vec_slot(int s, int g, int which, int rr) {
+    return 4 * ((s ^ (2 * which) ^ (g & 1)) & 3) + ((rr ^ g) & 3);
+}
+
 }  // namespace rk

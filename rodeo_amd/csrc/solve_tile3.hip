@@ -161,46 +161,41 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
 
 // ---- backward: one consumer wave + two producer waves per 4 tiles ----------------------------------------------
 // Time runs in "ticks" separated by workgroup barriers; in tick t the consumer smooths chunk t (16 steps) while
-// the producers prepare later chunks.  Producer p owns the chunks ch = p (mod 2); its work on chunk ch is split in
-// two phases, A in tick ch-2 (prefetch + predict + T) and B in tick ch-1 (pivoted LU + LDS writes), so that each
-// producer has two ticks per chunk and the two producers are always in opposite phases.  Chunk ch is handed over in
-// LDS buffer ch & 1 (written during tick ch-1, read during tick ch).
+// the producers prepare later chunks.  Producer q (of three) owns the chunks ch = q (mod 3); its work on chunk ch is
+// split in two phases, A in tick ch-2 (prefetch + predict + T) and B in tick ch-1 (pivoted LU + LDS writes), so in
+// every tick one producer is in phase A, one in phase B and one idle.  Chunk ch is handed over in LDS buffer ch & 1
+// (written during tick ch-1, read during tick ch).
 constexpr int CHUNK = 16;                       // time steps per hand-off
 constexpr int ITEM_BYTES = 3 * 128;              // per (step, tile): M-, G~^T, M_f tiles of 16 doubles
 constexpr int BUF_BYTES = CHUNK * 4 * ITEM_BYTES;   // 24 KiB
 
-// byte offset inside a buffer of element idx (= 4 r + c) of tile `which` of item (s, g); the XOR swizzle makes the
-// producer's 64 lanes (one item each, 256 B apart) hit distinct banks
+// byte offset inside a buffer of element idx (= 4 r + c) of tile `which` of item (s, g)
 __device__ __forceinline__ int lds_byte(int s, int g, int which, int idx) {
     const int item = s * 4 + g;
-    return item * ITEM_BYTES + which * 128 + ((idx ^ (item & 15)) << 3);
+    return item * ITEM_BYTES + which * 128 + (tile_slot(s, g, idx) << 3);
 }
 
-// Workgroup = 8 waves for 8 tiles (two groups of 4).  A workgroup's waves go to the CU's four SIMDs cyclically, so
-// waves w and w + 4 share a SIMD: the two consumers (waves 0, 1) get a SIMD each to themselves (waves 4, 5 exit at
-// once), and the four producer waves (2, 3, 6, 7) share the other two SIMDs.  This is a speed assumption only --
-// any placement gives the same results.
-__global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D, int dbg) {
+// Workgroup = 4 waves for 4 tiles: wave 0 consumes, waves 1..3 produce; a workgroup's waves go to the CU's four SIMDs
+// one each, and the CU holds two or three such workgroups (48 KiB of LDS each) that run out of step with each
+// other, which evens out the load of the SIMDs (a speed consideration only -- any placement gives the same results).
+__global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D, int dbg) {
     constexpr int P = 3;
-    __shared__ __attribute__((aligned(16))) char lds_all[2 * 2 * BUF_BYTES];
-    const int wave_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) char lds_all[2 * BUF_BYTES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;    // 0 = consumer; producers q = wave - 1 own ch = q (mod 3)
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * TILE_DOUBLES;
     const int n_chunks = (a.N - 1 + CHUNK - 1) / CHUNK;            // steps n = N-1 .. 1
 
     // constant entries of the hand-off tiles (row 3 = e_3; column 3 of G~^T = e_3) are written once
-    for (int i = threadIdx.x; i < 2 * 2 * 64 * 3 * 16; i += 512) {
+    for (int i = threadIdx.x; i < 2 * 64 * 3 * 16; i += 256) {
         const int idx = i & 15, which = (i >> 4) % 3, item = ((i >> 4) / 3) & 63, buf = i / (64 * 3 * 16);
         const double v = (idx == 15) ? 1.0 : 0.0;
         *(double*)(lds_all + buf * BUF_BYTES + lds_byte(item >> 2, item & 3, which, idx)) = v;
     }
     __syncthreads();
-    if (wave_id == 4 || wave_id == 5) return;                      // placeholders that keep the consumers' SIMDs free
 
-    const int grp = wave_id & 1;                                   // which group of 4 tiles
-    const int wave = wave_id < 2 ? 0 : (wave_id < 4 ? 1 : 2);       // 0 consumer, 1 / 2 producers of parity 0 / 1
-    const int tw = blockIdx.x * 2 + grp;                           // tile-wave index: tiles 4 tw .. 4 tw + 3
-    char* const lds_raw = lds_all + grp * 2 * BUF_BYTES;
+    const int tw = blockIdx.x;                                     // tile-wave index: tiles 4 tw .. 4 tw + 3
+    char* const lds_raw = lds_all;
     // this tile-wave's 64-double slice of the scratch tail (row 3 of its tiles: e_3)
     double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)tw * 64;
 
@@ -230,30 +225,36 @@ __global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* 
             for (int i = 0; i < TILE_DOUBLES; ++i) dst[i] = in[i];
         };
         if (p < n_chunks) fetch(p, bufE);
-        if (p + 2 < n_chunks) fetch(p + 2, bufO);
+        if (p + 3 < n_chunks) fetch(p + 3, bufO);
         double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P];
+        long long tW = 0, tF = 0, pA0 = 0;                                  // diagnostic build path (dbg & 8)
         auto phaseA = [&](int chA, double (&buf)[TILE_DOUBLES]) {
+            if (dbg & 8) pA0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int i = 0; i < P; ++i) {
 #pragma unroll
                 for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
                 mf[i] = buf[i * 4 + 3];
             }
-            if (chA + 4 < n_chunks) fetch(chA + 4, buf);         // refill this buffer for the chunk after next
+            if (dbg & 8) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tW += __builtin_amdgcn_s_memtime() - pA0; }
+            if (chA + 6 < n_chunks) fetch(chA + 6, buf);         // refill this buffer for the chunk after next
             __builtin_amdgcn_sched_barrier(0);
+            if (dbg & 8) tF += __builtin_amdgcn_s_memtime() - pA0;
             predict_block<P>(Q, R, mf, Sf, mp, Sp);              // pred[n+1] from filt[n]   (standard.py:57-59)
             mm_nt<P, P, P>(Sf, Q, T);                            // T = Sigma_f Q^T          (standard.py:175)
         };
+        long long tA = 0, tB = 0;                                  // diagnostic build path (dbg & 8)
         for (int t = -2; t < n_chunks; ++t) {
             const int chA = t + 2, chB = t + 1;
-            if ((chA & 1) == p) {
+            const long long p0 = (dbg & 8) ? __builtin_amdgcn_s_memtime() : 0;
+            if (chA % 3 == p) {
                 // ---- phase A of chunk chA: (re)fill the fetch buffer, predict, T ----
                 if (chA < n_chunks && !(dbg & 1)) {
-                    if ((chA >> 1) & 1) phaseA(chA, bufO); else phaseA(chA, bufE);
+                    if ((chA / 3) & 1) phaseA(chA, bufO); else phaseA(chA, bufE);
                 }
-            } else {
+            } else if (chB >= 0 && chB % 3 == p) {
                 // ---- phase B of chunk chB: G = solve(Sigma-, T^T)^T (standard.py:176), hand-off ----
-                if (chB >= 0 && chB < n_chunks && !(dbg & 1)) {
+                if (chB < n_chunks && !(dbg & 1)) {
                     double A[P][P], X[P][P];
 #pragma unroll
                     for (int i = 0; i < P; ++i)
@@ -277,8 +278,14 @@ __global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* 
                     }
                 }
             }
+            if (dbg & 8) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const long long dt = __builtin_amdgcn_s_memtime() - p0;
+                if (chA % 3 == p) tA += dt; else if (chB >= 0 && chB % 3 == p) tB += dt;
+            }
             __syncthreads();
         }
+        if ((dbg & 8) && tw == 0 && p == 0 && lane == 0) { dump[20] = (double)tA; dump[24] = (double)tB; dump[28] = (double)tW; dump[32] = (double)tF; }
     } else {
         // ---------------- consumer: the carry recursion on MFMA tiles ----------------
         const TileCoord tc = tile_coord<1>(tw, lane, n_tiles);              // (b, blk) not needed here
@@ -293,6 +300,7 @@ __global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* 
         for (int k = 0; k < 4; ++k) roff[k] = lds_byte(k, g, 0, idx) - k * 4 * ITEM_BYTES;
         double Ms = base[(size_t)a.N * ostride];                    // carry = filt[N]  (solve.py:279-282)
         const long long stamp0 = (dbg & 4) ? __builtin_amdgcn_s_memtime() : 0;     // diagnostic build path only
+        long long busy = 0, t_ld = 0, t_chain = 0;
         __syncthreads();                                            // tick -2
         __syncthreads();                                            // tick -1: chunk 0 is in LDS
         for (int t = 0; t < n_chunks; ++t) {
@@ -300,6 +308,7 @@ __global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* 
             const int n_hi = a.N - 1 - t * CHUNK;
             const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CHUNK ? CHUNK : n_hi);   // steps n_hi .. n_hi-cnt+1
             double* o = base + (size_t)n_hi * ostride;
+            const long long c0 = (dbg & 4) ? __builtin_amdgcn_s_memtime() : 0;
             if (!(dbg & 2)) {
                 if (cnt == CHUNK) {
                     // full chunk, branch-free: all 48 hand-off values are read from LDS up front (immediate offsets),
@@ -331,10 +340,19 @@ __global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* 
                     }
                 }
             }
+            if (dbg & 4) {
+                t_chain += __builtin_amdgcn_s_memtime() - c0;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                busy += __builtin_amdgcn_s_memtime() - c0;
+            }
             __syncthreads();
         }
-        if ((dbg & 4) && tw == 0 && lane == 3)      // shader cycles of the whole consumer loop -> scratch tail
+        if ((dbg & 4) && tw == 0 && lane == 3) {    // diagnostic build path: loop cycles and cycles outside barriers
             dump[lane] = (double)(__builtin_amdgcn_s_memtime() - stamp0);
+            dump[lane + 4] = (double)busy;
+            dump[lane + 8] = (double)t_ld;
+            dump[lane + 12] = (double)t_chain;
+        }
     }
 }
 
@@ -344,16 +362,16 @@ __global__ void __launch_bounds__(512) bwd_mv_tile3_kernel(SolveArgs a, double* 
 // solve.py:179) and the Philox normals; the consumer's dependent chain is ONE MFMA per step:
 //     x = MF(G~^T, x - mu-, mu_f + L~ z)        (x, mu-, ... in row form: lane (r, g, c) holds component r)
 // The terminal draw x_N ~ N(filt[N]) (solve.py:182-186) is the same step with G = 0.  Hand-off item: 256 B.
-constexpr int SIM_ITEM = 256;                   // [G~^T tile 128 B | mu- 32 B | mu_f + L z 32 B | pad]
+constexpr int SIM_ITEM = 256;                   // [G~^T tile 128 B | 128 B vector area: mu-, mu_f + L z (swizzled)]
 constexpr int SIM_BUF = CHUNK * 4 * SIM_ITEM;   // 16 KiB
 
 __device__ __forceinline__ int sim_tile_byte(int s, int g, int idx) {
     const int item = s * 4 + g;
-    return item * SIM_ITEM + ((idx ^ (item & 15)) << 3);
+    return item * SIM_ITEM + (tile_slot(s, g, idx) << 3);
 }
 __device__ __forceinline__ int sim_vec_byte(int s, int g, int which, int rr) {
     const int item = s * 4 + g;
-    return item * SIM_ITEM + 128 + which * 32 + ((rr ^ (item & 3)) << 3);
+    return item * SIM_ITEM + 128 + (vec_slot(s, g, which, rr) << 3);
 }
 
 __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D) {
@@ -383,12 +401,13 @@ __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double*
         double Q[P][P], R[P][P];
         load_block_consts<P>(a, blk, b, Q, R);
         const double* tin = tiles + (size_t)tau * TILE_DOUBLES;
-        int woff[9], voff[3];
+        int woff[9], voff[3], voff1[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) woff[i * 3 + j] = sim_tile_byte(s, g, i * 4 + j);
             voff[i] = sim_vec_byte(s, g, 0, i);
+            voff1[i] = sim_vec_byte(s, g, 1, i);
         }
         double bufE[TILE_DOUBLES], bufO[TILE_DOUBLES];
         auto fetch = [&](int ch, double (&dst)[TILE_DOUBLES]) {
@@ -450,7 +469,7 @@ __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double*
 #pragma unroll
                         for (int j = 0; j < P; ++j) *(double*)(o + woff[i * 3 + j]) = G[j][i];      // G~^T
                         *(double*)(o + voff[i]) = term ? 0.0 : mp[i];
-                        *(double*)(o + voff[i] + 32) = w;                                          // mu_f + L z
+                        *(double*)(o + voff1[i]) = w;                                               // mu_f + L z
                     }
                 }
             }
@@ -465,11 +484,12 @@ __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double*
         const size_t xstride = (size_t)D * P * a.B;
         double* bx = st ? a.x + ((size_t)blk * P + r) * a.B + b : dump + lane;
         const size_t sx = st ? xstride : 0;
-        int roff[4], rvec[4];
+        int roff[4], rvec[4], rvec1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             roff[k] = sim_tile_byte(k, g, idx) - k * 4 * SIM_ITEM;
             rvec[k] = sim_vec_byte(k, g, 0, r) - k * 4 * SIM_ITEM;
+            rvec1[k] = sim_vec_byte(k, g, 1, r) - k * 4 * SIM_ITEM;
         }
         double x = 0.0;
         __syncthreads();
@@ -479,17 +499,18 @@ __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double*
             const int n_hi = a.N - t * CHUNK;
             const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CHUNK ? CHUNK : n_hi);
             double* o = bx + (size_t)n_hi * sx;
-            auto step = [&](const char* q, const char* qv) {
-                const double Gt = *(const double*)(q), mp = *(const double*)(qv), mfw = *(const double*)(qv + 32);
+            auto step = [&](const char* q, const char* qv, const char* qw) {
+                const double Gt = *(const double*)(q), mp = *(const double*)(qv), mfw = *(const double*)(qw);
                 x = MF(Gt, x - mp, mfw);
                 o[0] = x;
                 o -= sx;
             };
             if (cnt == CHUNK) {
 #pragma unroll
-                for (int s = 0; s < CHUNK; ++s) step(in + roff[s & 3] + s * 4 * SIM_ITEM, in + rvec[s & 3] + s * 4 * SIM_ITEM);
+                for (int s = 0; s < CHUNK; ++s) step(in + roff[s & 3] + s * 4 * SIM_ITEM, in + rvec[s & 3] + s * 4 * SIM_ITEM,
+                                                     in + rvec1[s & 3] + s * 4 * SIM_ITEM);
             } else {
-                for (int s = 0; s < cnt; ++s) step(in + sim_tile_byte(s, g, idx), in + sim_vec_byte(s, g, 0, r));
+                for (int s = 0; s < cnt; ++s) step(in + sim_tile_byte(s, g, idx), in + sim_vec_byte(s, g, 0, r), in + sim_vec_byte(s, g, 1, r));
             }
             __syncthreads();
         }
@@ -499,6 +520,9 @@ __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double*
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------------------------
+// Note on occupancy: the forward recursion is one dependent chain per wave (about 290 cycles per step: 7 MFMAs + 27
+// VALU operations issued in order), so a launch takes n_steps x that latency however few waves there are; fewer tiles
+// per wave or more waves per workgroup change nothing (measured, round 1) -- only more trajectories raise throughput.
 template <class RHS>
 static int launch_fwd_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles) {
     const dim3 grid(div_up(a.B * RHS::D, 4)), block(64);
@@ -544,7 +568,7 @@ int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     }
     if (a.N < 2) return rc;
     LaunchTimer t(h, "bwd_mv_tile3_kernel");
-    hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 8)), dim3(512), 0, h->stream, a, tiles, a.D, (c->flags >> 16) & 7);
+    hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(256), 0, h->stream, a, tiles, a.D, (c->flags >> 16) & 15);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

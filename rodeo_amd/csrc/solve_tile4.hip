@@ -150,11 +150,11 @@ constexpr int BUF4 = CH4 * 4 * ITEM4;            // 32 KiB
 
 __device__ __forceinline__ int lds4_tile(int s, int g, int which, int idx) {
     const int item = s * 4 + g;
-    return item * ITEM4 + which * 128 + ((idx ^ (item & 15)) << 3);
+    return item * ITEM4 + which * 128 + (tile_slot(s, g, idx) << 3);
 }
 __device__ __forceinline__ int lds4_vec(int s, int g, int which, int rr) {
     const int item = s * 4 + g;
-    return item * ITEM4 + 384 + which * 32 + ((rr ^ (item & 3)) << 3);
+    return item * ITEM4 + 384 + (vec_slot(s, g, which, rr) << 3);
 }
 
 template <int D>
@@ -183,11 +183,11 @@ __global__ void __launch_bounds__(512) bwd_mv_tile4_kernel(SolveArgs a, double* 
         double Q[P][P], R[P][P];
         load_block_consts<P>(a, blk, b, Q, R);
         const double* tin = tiles + (size_t)tau * T4_DOUBLES;
-        int woff[16], voff[4];
+        int woff[16], voff[4], voff1[4];
 #pragma unroll
         for (int i = 0; i < 16; ++i) woff[i] = lds4_tile(s, g, 0, i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) voff[i] = lds4_vec(s, g, 0, i);
+        for (int i = 0; i < 4; ++i) { voff[i] = lds4_vec(s, g, 0, i); voff1[i] = lds4_vec(s, g, 1, i); }
         double bufE[T4_DOUBLES], bufO[T4_DOUBLES];
         auto fetch = [&](int ch, double (&dst)[T4_DOUBLES]) {
             int n = a.N - 1 - ch * CH4 - s;
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(512) bwd_mv_tile4_kernel(SolveArgs a, double* 
                             *(double*)(o + woff[i * 4 + j] + 256) = Sf[i][j];
                         }
                         *(double*)(o + voff[i]) = mp[i];
-                        *(double*)(o + voff[i] + 32) = mf[i];
+                        *(double*)(o + voff1[i]) = mf[i];
                     }
                 }
             }
@@ -253,11 +253,12 @@ __global__ void __launch_bounds__(512) bwd_mv_tile4_kernel(SolveArgs a, double* 
         // carry = filt[N]  (solve.py:279-282); the mean in row form
         double Ss = tc.valid ? tiles[(size_t)a.N * tstride + (size_t)tc.tau * T4_DOUBLES + idx] : 0.0;
         double ms = tc.valid ? tiles[(size_t)a.N * tstride + (size_t)tc.tau * T4_DOUBLES + 16 + r] : 0.0;
-        int roff[4], rvec[4];
+        int roff[4], rvec[4], rvec1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             roff[k] = lds4_tile(k, g, 0, idx) - k * 4 * ITEM4;
             rvec[k] = lds4_vec(k, g, 0, r) - k * 4 * ITEM4;
+            rvec1[k] = lds4_vec(k, g, 1, r) - k * 4 * ITEM4;
         }
         __syncthreads();                                            // tick -2
         __syncthreads();                                            // tick -1: chunk 0 is in LDS
@@ -267,9 +268,9 @@ __global__ void __launch_bounds__(512) bwd_mv_tile4_kernel(SolveArgs a, double* 
             const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CH4 ? CH4 : n_hi);
             double* oS = bS + (size_t)n_hi * sS;
             double* oM = bM + (size_t)n_hi * sM;
-            auto step = [&](const char* q, const char* qv) {
+            auto step = [&](const char* q, const char* qv, const char* qw) {
                 const double Sp = *(const double*)(q), Gt = *(const double*)(q + 128), Sf = *(const double*)(q + 256);
-                const double mp = *(const double*)(qv), mf = *(const double*)(qv + 32);
+                const double mp = *(const double*)(qv), mf = *(const double*)(qw);
                 const double V1 = MF(Ss - Sp, Gt, 0.0);             // (G D)^T
                 ms = MF(Gt, ms - mp, mf);                           // mu_f + G (mu_s - mu-)     (standard.py:213-214)
                 Ss = MF(V1, Gt, Sf);                                // Sigma_f + G D G^T         (standard.py:215-216)
@@ -278,9 +279,10 @@ __global__ void __launch_bounds__(512) bwd_mv_tile4_kernel(SolveArgs a, double* 
             };
             if (cnt == CH4) {
 #pragma unroll
-                for (int s = 0; s < CH4; ++s) step(in + roff[s & 3] + s * 4 * ITEM4, in + rvec[s & 3] + s * 4 * ITEM4);
+                for (int s = 0; s < CH4; ++s) step(in + roff[s & 3] + s * 4 * ITEM4, in + rvec[s & 3] + s * 4 * ITEM4,
+                                                   in + rvec1[s & 3] + s * 4 * ITEM4);
             } else {
-                for (int s = 0; s < cnt; ++s) step(in + lds4_tile(s, g, 0, idx), in + lds4_vec(s, g, 0, r));
+                for (int s = 0; s < cnt; ++s) step(in + lds4_tile(s, g, 0, idx), in + lds4_vec(s, g, 0, r), in + lds4_vec(s, g, 1, r));
             }
             __syncthreads();
         }
