@@ -29,9 +29,6 @@ namespace rk {
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
-// hidden measurement switches in rk_solve_cfg.flags (not part of the ABI): bits 16..19 = diagnostic modes of
-// bwd_mv_tile3_kernel
-
 #define RK_HIP(call)                                                          \
     do {                                                                      \
         hipError_t e__ = (call);                                              \

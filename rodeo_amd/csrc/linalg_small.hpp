@@ -71,9 +71,9 @@ __device__ __forceinline__ double dot(const double (&a)[K], const double (&b)[K]
 // first-maximum pivot search, right-looking elimination).  A (PxP) and B (PxNR) are destroyed; B <- X.
 // Row swaps are predicated selects so the arrays stay in registers.  A singular pivot yields inf/NaN, silently,
 // like the reference.
+// The two halves are separate functions so that a kernel can run them in different pipeline stages.
 template <int P, int NR>
-__device__ __forceinline__ void lu_solve(double (&A)[P][P], double (&B)[P][NR]) {
-    double rpiv[P];
+__device__ __forceinline__ void lu_factor_fwd(double (&A)[P][P], double (&B)[P][NR], double (&rpiv)[P]) {
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         // pivot search in column k (first maximum of |a_ik|, i >= k)
@@ -112,7 +112,10 @@ __device__ __forceinline__ void lu_solve(double (&A)[P][P], double (&B)[P][NR]) 
             for (int j = 0; j < NR; ++j) B[i][j] = fma(-l, B[k][j], B[i][j]);
         }
     }
-    // back substitution with the upper factor
+}
+// back substitution with the upper factor left in A by lu_factor_fwd
+template <int P, int NR>
+__device__ __forceinline__ void lu_back(const double (&A)[P][P], double (&B)[P][NR], const double (&rpiv)[P]) {
 #pragma unroll
     for (int k = P - 1; k >= 0; --k) {
 #pragma unroll
@@ -123,6 +126,12 @@ __device__ __forceinline__ void lu_solve(double (&A)[P][P], double (&B)[P][NR]) 
             B[k][j] = s * rpiv[k];
         }
     }
+}
+template <int P, int NR>
+__device__ __forceinline__ void lu_solve(double (&A)[P][P], double (&B)[P][NR]) {
+    double rpiv[P];
+    lu_factor_fwd<P, NR>(A, B, rpiv);
+    lu_back<P, NR>(A, B, rpiv);
 }
 
 // Lower-triangular F with F F^T = A for symmetric positive semi-definite A (reads the lower triangle); a

@@ -70,4 +70,22 @@ __device__ __forceinline__ int vec_slot(int s, int g, int which, int rr) {
     return 4 * ((s ^ (2 * which) ^ (g & 1)) & 3) + ((rr ^ g) & 3);
 }
 
+// ---- global -> LDS prefetch without registers (LDS-DMA) ----
+// A prefetch held in VGPRs across loop iterations makes hipcc land the loads in temporaries and copy them into the
+// loop-carried registers behind s_waitcnt vmcnt(0) at the end of the issuing block, i.e. it exposes the whole HBM
+// latency (measured in bwd_mv_tile3_kernel: 2,400 instead of 600 cycles per phase).  global_load_lds_dwordx4 has no
+// register destination: each lane's 16 bytes at `src` go to LDS byte address lds_dst + 16 * lane.  hipcc does not
+// count these loads: the issuing wave waits with lds_dma_wait_all() before it reads the zone (cdna_hip_programming.md
+// section 8, "What hipcc does not do"), and a zone is private to its wave, so no barrier is involved.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_dst /* wave-uniform */) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 }  // namespace rk

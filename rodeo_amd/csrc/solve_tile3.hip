@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
 constexpr int CHUNK = 16;                       // time steps per hand-off
 constexpr int ITEM_BYTES = 3 * 128;              // per (step, tile): M-, G~^T, M_f tiles of 16 doubles
 constexpr int BUF_BYTES = CHUNK * 4 * ITEM_BYTES;   // 24 KiB
+constexpr int ZONE_BYTES = 64 * TILE_DOUBLES * 8;   // 6 KiB: one producer's prefetched filt tiles (64 lanes x 96 B)
 
 // byte offset inside a buffer of element idx (= 4 r + c) of tile `which` of item (s, g)
 __device__ __forceinline__ int lds_byte(int s, int g, int which, int idx) {
@@ -178,9 +179,10 @@ __device__ __forceinline__ int lds_byte(int s, int g, int which, int idx) {
 // Workgroup = 4 waves for 4 tiles: wave 0 consumes, waves 1..3 produce; a workgroup's waves go to the CU's four SIMDs
 // one each, and the CU holds two or three such workgroups (48 KiB of LDS each) that run out of step with each
 // other, which evens out the load of the SIMDs (a speed consideration only -- any placement gives the same results).
-__global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D, int dbg) {
+__global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D) {
     constexpr int P = 3;
     __shared__ __attribute__((aligned(16))) char lds_all[2 * BUF_BYTES];
+    __shared__ __attribute__((aligned(16))) char zones[3 * ZONE_BYTES];      // the producers' prefetch landing zones
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;    // 0 = consumer; producers q = wave - 1 own ch = q (mod 3)
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * TILE_DOUBLES;
@@ -214,56 +216,62 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) woff[i * 4 + j] = lds_byte(s, g, 0, i * 4 + j);
-        // filt tiles of this producer's chunks are fetched two own chunks (= four ticks) ahead into two statically
-        // named register buffers (global latency under load is longer than one tick)
-        double bufE[TILE_DOUBLES], bufO[TILE_DOUBLES];
-        auto fetch = [&](int ch, double (&dst)[TILE_DOUBLES]) {
-            int n = a.N - 1 - ch * CHUNK - s;
-            n = n < 1 ? 1 : n;                                   // clamped loads are never used
-            const double* in = tin + (size_t)n * tstride;
+        // The filt tiles of this producer's next chunk are prefetched by LDS-DMA into the wave's own 6 KiB landing zone
+        // (piece k = bytes 16k..16k+15 of every lane's 96-byte tile) right after phase A has read the zone, three
+        // ticks before they are needed; no prefetch lives in registers (mfma_tile.hpp, lds_dma16).
+        char* const zone = zones + p * ZONE_BYTES;
+        const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
+        auto fetch = [&](int ch) {
+            const int n = a.N - 1 - ch * CHUNK - s;
+            const char* in = (const char*)(tin + (size_t)(n < 1 ? 1 : n) * tstride);     // clamped loads are never handed over
 #pragma unroll
-            for (int i = 0; i < TILE_DOUBLES; ++i) dst[i] = in[i];
+            for (int k = 0; k < 6; ++k) lds_dma16(in + 16 * k, zone_lds + 1024 * k);
         };
-        if (p < n_chunks) fetch(p, bufE);
-        if (p + 3 < n_chunks) fetch(p + 3, bufO);
-        double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P];
-        long long tW = 0, tF = 0, pA0 = 0;                                  // diagnostic build path (dbg & 8)
-        auto phaseA = [&](int chA, double (&buf)[TILE_DOUBLES]) {
-            if (dbg & 8) pA0 = __builtin_amdgcn_s_memtime();
+        if (p < n_chunks) fetch(p);
+        // Chunk ch passes through three stages in the ticks ch-3, ch-2, ch-1 (one workgroup barrier per tick), so in
+        // every tick the three producers each run a different stage of three different chunks: equal work per SIMD
+        // and tick.  All state between stages stays in this wave's registers.
+        double mf[P], Sf[P][P], mp[P], Sp[P][P], A[P][P], X[P][P], rpiv[P];
+        for (int t = -3; t < n_chunks; ++t) {
+            const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
+            if (ch1 % 3 == p) {
+                // ---- stage 1 of chunk ch1: take the fetched tiles, start the next fetch, predict ----
+                if (ch1 < n_chunks) {
+                    lds_dma_wait_all();
+                    double buf[TILE_DOUBLES];
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
+                    for (int k = 0; k < 6; ++k) {
+                        const double2 v = *(const double2*)(zone + 1024 * k + 16 * lane);
+                        buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
+                    }
+                    lds_reads_done();
+                    if (ch1 + 3 < n_chunks) fetch(ch1 + 3);
 #pragma unroll
-                for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
-                mf[i] = buf[i * 4 + 3];
-            }
-            if (dbg & 8) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tW += __builtin_amdgcn_s_memtime() - pA0; }
-            if (chA + 6 < n_chunks) fetch(chA + 6, buf);         // refill this buffer for the chunk after next
-            __builtin_amdgcn_sched_barrier(0);
-            if (dbg & 8) tF += __builtin_amdgcn_s_memtime() - pA0;
-            predict_block<P>(Q, R, mf, Sf, mp, Sp);              // pred[n+1] from filt[n]   (standard.py:57-59)
-            mm_nt<P, P, P>(Sf, Q, T);                            // T = Sigma_f Q^T          (standard.py:175)
-        };
-        long long tA = 0, tB = 0;                                  // diagnostic build path (dbg & 8)
-        for (int t = -2; t < n_chunks; ++t) {
-            const int chA = t + 2, chB = t + 1;
-            const long long p0 = (dbg & 8) ? __builtin_amdgcn_s_memtime() : 0;
-            if (chA % 3 == p) {
-                // ---- phase A of chunk chA: (re)fill the fetch buffer, predict, T ----
-                if (chA < n_chunks && !(dbg & 1)) {
-                    if ((chA / 3) & 1) phaseA(chA, bufO); else phaseA(chA, bufE);
+                    for (int i = 0; i < P; ++i) {
+#pragma unroll
+                        for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
+                        mf[i] = buf[i * 4 + 3];
+                    }
+                    predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
                 }
-            } else if (chB >= 0 && chB % 3 == p) {
-                // ---- phase B of chunk chB: G = solve(Sigma-, T^T)^T (standard.py:176), hand-off ----
-                if (chB < n_chunks && !(dbg & 1)) {
-                    double A[P][P], X[P][P];
+            } else if (ch2 >= 0 && ch2 % 3 == p) {
+                // ---- stage 2 of chunk ch2: T^T = (Sigma_f Q^T)^T (standard.py:175), LU of Sigma-, forward sweep ----
+                if (ch2 < n_chunks) {
+                    double T[P][P];
+                    mm_nt<P, P, P>(Sf, Q, T);
 #pragma unroll
                     for (int i = 0; i < P; ++i)
 #pragma unroll
                         for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
-                    lu_solve<P, P>(A, X);                            // X = G^T
-                    const int n = a.N - 1 - chB * CHUNK - s;
+                    lu_factor_fwd<P, P>(A, X, rpiv);
+                }
+            } else if (ch3 >= 0) {
+                // ---- stage 3 of chunk ch3: back substitution, X = solve(Sigma-, T^T) = G^T (standard.py:176), hand-off ----
+                if (ch3 < n_chunks) {
+                    lu_back<P, P>(A, X, rpiv);
+                    const int n = a.N - 1 - ch3 * CHUNK - s;
                     if (n >= 1) {
-                        char* o = lds_raw + (chB & 1) * BUF_BYTES;
+                        char* o = lds_raw + (ch3 & 1) * BUF_BYTES;
 #pragma unroll
                         for (int i = 0; i < P; ++i) {
 #pragma unroll
@@ -278,17 +286,12 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
                     }
                 }
             }
-            if (dbg & 8) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const long long dt = __builtin_amdgcn_s_memtime() - p0;
-                if (chA % 3 == p) tA += dt; else if (chB >= 0 && chB % 3 == p) tB += dt;
-            }
             __syncthreads();
         }
-        if ((dbg & 8) && tw == 0 && p == 0 && lane == 0) { dump[20] = (double)tA; dump[24] = (double)tB; dump[28] = (double)tW; dump[32] = (double)tF; }
     } else {
         // ---------------- consumer: the carry recursion on MFMA tiles ----------------
         const TileCoord tc = tile_coord<1>(tw, lane, n_tiles);              // (b, blk) not needed here
+        __builtin_amdgcn_s_setprio(3);      // the dependent chain is the critical path: win issue arbitration on this SIMD
         const int r = tc.r, g = tc.g, c = tc.c, idx = r * 4 + c;
         const bool st = tc.valid && r < 3;
         // lanes without a slot (row 3, tiles past the end) read and write the scratch tail with stride 0: row 3 of
@@ -299,8 +302,7 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
 #pragma unroll
         for (int k = 0; k < 4; ++k) roff[k] = lds_byte(k, g, 0, idx) - k * 4 * ITEM_BYTES;
         double Ms = base[(size_t)a.N * ostride];                    // carry = filt[N]  (solve.py:279-282)
-        const long long stamp0 = (dbg & 4) ? __builtin_amdgcn_s_memtime() : 0;     // diagnostic build path only
-        long long busy = 0, t_ld = 0, t_chain = 0;
+        __syncthreads();                                            // tick -3
         __syncthreads();                                            // tick -2
         __syncthreads();                                            // tick -1: chunk 0 is in LDS
         for (int t = 0; t < n_chunks; ++t) {
@@ -308,8 +310,7 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
             const int n_hi = a.N - 1 - t * CHUNK;
             const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CHUNK ? CHUNK : n_hi);   // steps n_hi .. n_hi-cnt+1
             double* o = base + (size_t)n_hi * ostride;
-            const long long c0 = (dbg & 4) ? __builtin_amdgcn_s_memtime() : 0;
-            if (!(dbg & 2)) {
+            {
                 if (cnt == CHUNK) {
                     // full chunk, branch-free: all 48 hand-off values are read from LDS up front (immediate offsets),
                     // then the 16-step dependent chain  D = Ms - M- ; V = MF(D, G~^T) ; Ms = MF(V, G~^T, M_f)
@@ -340,18 +341,7 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
                     }
                 }
             }
-            if (dbg & 4) {
-                t_chain += __builtin_amdgcn_s_memtime() - c0;
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                busy += __builtin_amdgcn_s_memtime() - c0;
-            }
             __syncthreads();
-        }
-        if ((dbg & 4) && tw == 0 && lane == 3) {    // diagnostic build path: loop cycles and cycles outside barriers
-            dump[lane] = (double)(__builtin_amdgcn_s_memtime() - stamp0);
-            dump[lane + 4] = (double)busy;
-            dump[lane + 8] = (double)t_ld;
-            dump[lane + 12] = (double)t_chain;
         }
     }
 }
@@ -568,7 +558,7 @@ int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     }
     if (a.N < 2) return rc;
     LaunchTimer t(h, "bwd_mv_tile3_kernel");
-    hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(256), 0, h->stream, a, tiles, a.D, (c->flags >> 16) & 15);
+    hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(256), 0, h->stream, a, tiles, a.D);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;
