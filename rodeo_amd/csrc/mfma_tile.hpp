@@ -85,7 +85,32 @@ __device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_dst /* w
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// s_waitcnt vmcnt(0) as the builtin (0x0F70 = vmcnt 0, expcnt 7, lgkmcnt 15), which hipcc's own wait bookkeeping sees.
+// Call it once after the kernel's ordinary global loads and before the first lds_dma16: otherwise hipcc, which does
+// not count the DMA instructions, later waits for "its" outstanding loads with a counted vmcnt(N) that in fact drains
+// the DMAs in flight (measured: 900-1,400 cycles per stage in bwd_mv_tile3_kernel).
+__device__ __forceinline__ void lds_dma_wait_all() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One 8-byte store per lane of `mask` at row + voff, with the row pointer in SGPRs: a per-lane 64-bit pointer would
+// cost a VALU add per store (moving it from row to row), and VALU work does not hide in the gaps of a dependent MFMA
+// chain (profiles/r01_probe3_mfma_valu_serialize.log).  EXEC must be all ones on entry (whole-wave code only).
+// hipcc does not see inside the statement, so the wait states an MFMA result needs before a VMEM instruction may read
+// it (9 for the 4-pass f64 MFMA: hipcc itself emits s_nop 8 there) are the caller's business:
+//   store_f64_masked_after: `after` is a VALU result computed from v, which orders the store behind that instruction
+//                           (>= 9 cycles with the s_nop 4 hipcc puts before the VALU read, the VALU op and s_nop 0);
+//   store_f64_masked_mfma : v comes straight from an MFMA, the statement opens with s_nop 8.
+__device__ __forceinline__ void store_f64_masked_after(const void* row /* wave-uniform */, unsigned voff, double v,
+                                                       unsigned long long mask /* wave-uniform */, double after) {
+    asm volatile("s_nop 0\n\ts_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                 :: "v"(voff), "v"(v), "s"(row), "s"(mask), "v"(after) : "memory");
+}
+__device__ __forceinline__ void store_f64_masked_mfma(const void* row, unsigned voff, double v, unsigned long long mask) {
+    asm volatile("s_nop 8\n\ts_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                 :: "v"(voff), "v"(v), "s"(row), "s"(mask) : "memory");
+}
 
 }  // namespace rk

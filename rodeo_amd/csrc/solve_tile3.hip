@@ -32,6 +32,7 @@
 namespace rk {
 
 constexpr int TILE_DOUBLES = 12;     // 3 rows x [Sigma(3) | mu] per (time step, tile)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct TileCoord {
     int r, g, c;          // row, tile-in-wave, column
@@ -210,23 +211,32 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
         const int b = tau / D, blk = tau - b * D;
         double Q[P][P], R[P][P];
         load_block_consts<P>(a, blk, b, Q, R);
-        const double* tin = tiles + (size_t)tau * TILE_DOUBLES;
         int woff[12];                                              // LDS byte offsets of the 12 slots this lane writes
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) woff[i * 4 + j] = lds_byte(s, g, 0, i * 4 + j);
         // The filt tiles of this producer's next chunk are prefetched by LDS-DMA into the wave's own 6 KiB landing zone
-        // (piece k = bytes 16k..16k+15 of every lane's 96-byte tile) right after phase A has read the zone, three
-        // ticks before they are needed; no prefetch lives in registers (mfma_tile.hpp, lds_dma16).
+        // right after stage 1 has read the zone, three ticks before they are needed; no prefetch lives in registers
+        // (mfma_tile.hpp, lds_dma16).  The zone is the image of the chunk's 16 rows x 384 contiguous bytes (this
+        // tile-wave's 4 tiles in 16 time rows): piece j = 64 i + lane of instruction i is bytes 16 (j % 24) of row
+        // j / 24, so one instruction reads 2 2/3 whole rows (measured: 64 scattered 16-byte pieces per instruction
+        // cost 185-280 cycles of issue each, whole rows about a quarter of that).
         char* const zone = zones + p * ZONE_BYTES;
         const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
-        auto fetch = [&](int ch) {
-            const int n = a.N - 1 - ch * CHUNK - s;
-            const char* in = (const char*)(tin + (size_t)(n < 1 ? 1 : n) * tstride);     // clamped loads are never handed over
+        int frow[6], fcol[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) lds_dma16(in + 16 * k, zone_lds + 1024 * k);
+        for (int i = 0; i < 6; ++i) { const int j = 64 * i + lane; frow[i] = j / 24; fcol[i] = (j % 24) * 16; }
+        const char* const wave_tiles = (const char*)(tiles + (size_t)tw * 4 * TILE_DOUBLES);
+        auto fetch = [&](int ch) {
+            const int n_hi = a.N - 1 - ch * CHUNK;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int n = n_hi - frow[i];                        // rows past the start (n < 1) are clamped, never handed over
+                lds_dma16(wave_tiles + (size_t)(n < 1 ? 1 : n) * tstride * 8 + fcol[i], zone_lds + 1024 * i);
+            }
         };
+        lds_dma_wait_all();                                        // retire the loads of Q, R before the first DMA
         if (p < n_chunks) fetch(p);
         // Chunk ch passes through three stages in the ticks ch-3, ch-2, ch-1 (one workgroup barrier per tick), so in
         // every tick the three producers each run a different stage of three different chunks: equal work per SIMD
@@ -241,7 +251,7 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
                     double buf[TILE_DOUBLES];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) {
-                        const double2 v = *(const double2*)(zone + 1024 * k + 16 * lane);
+                        const double2 v = *(const double2*)(zone + 96 * lane + 16 * k);      // lane = 4 s + g
                         buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
                     }
                     lds_reads_done();
@@ -302,6 +312,12 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
 #pragma unroll
         for (int k = 0; k < 4; ++k) roff[k] = lds_byte(k, g, 0, idx) - k * 4 * ITEM_BYTES;
         double Ms = base[(size_t)a.N * ostride];                    // carry = filt[N]  (solve.py:279-282)
+        // full chunks store with a scalar row pointer + this lane's byte offset in the tile-wave's 384 bytes
+        const char* const wave_rows = (const char*)(tiles + (size_t)tw * 4 * TILE_DOUBLES);
+        const size_t row_bytes = tstride * sizeof(double);
+        const unsigned bvoff = st ? (unsigned)((g * TILE_DOUBLES + idx) * sizeof(double)) : 0x80000000u;   // or: out of range
+        const bool buffer_ok = (CHUNK - 1) * row_bytes + 384 < 0x7fffffffull;      // one chunk's rows within a 2 GiB buffer window
+        const int chunk_span = (int)((CHUNK - 1) * row_bytes + 384);
         __syncthreads();                                            // tick -3
         __syncthreads();                                            // tick -2
         __syncthreads();                                            // tick -1: chunk 0 is in LDS
@@ -311,24 +327,38 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
             const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CHUNK ? CHUNK : n_hi);   // steps n_hi .. n_hi-cnt+1
             double* o = base + (size_t)n_hi * ostride;
             {
-                if (cnt == CHUNK) {
-                    // full chunk, branch-free: all 48 hand-off values are read from LDS up front (immediate offsets),
-                    // then the 16-step dependent chain  D = Ms - M- ; V = MF(D, G~^T) ; Ms = MF(V, G~^T, M_f)
+                if (cnt == CHUNK && buffer_ok) {
+                    // full chunk, branch-free (immediate LDS offsets): the 16-step dependent chain
+                    //     D = Ms - M- ; V = MF(D, G~^T) ; Ms = MF(V, G~^T, M_f)              (standard.py:213-216)
+                    // Every instruction of this wave sits on that chain (VALU, LDS and memory instructions do not
+                    // overlap its MFMAs: profiles/r01_probe6_bwd_consumer.log), so a step is two MFMAs, one add, three
+                    // LDS reads issued LOOKAHEAD steps early (at most 15 LDS operations can be outstanding per wave,
+                    // so reading everything up front only stalls) and one buffer store: scalar row offset, no pointer
+                    // arithmetic, lanes without a slot dropped by the range check.
+                    constexpr int LOOKAHEAD = 4;
                     double Mp[CHUNK], Gt[CHUNK], Mf[CHUNK];
-#pragma unroll
-                    for (int s = 0; s < CHUNK; ++s) {
+                    auto load = [&](int s) {
                         const char* q = in + roff[s & 3] + s * 4 * ITEM_BYTES;
                         Mp[s] = *(const double*)(q);
                         Gt[s] = *(const double*)(q + 128);
                         Mf[s] = *(const double*)(q + 256);
-                    }
+                    };
+#pragma unroll
+                    for (int s = 0; s < LOOKAHEAD; ++s) load(s);
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(wave_rows + (size_t)(n_hi - (CHUNK - 1)) * row_bytes), 0, chunk_span, 0x00020000);
+                    double Dm = Ms - Mp[0];
 #pragma unroll
                     for (int s = 0; s < CHUNK; ++s) {
-                        const double Dm = Ms - Mp[s];
+                        if (s + LOOKAHEAD < CHUNK) load(s + LOOKAHEAD);
+                        __builtin_amdgcn_sched_barrier(0);
                         const double V1 = MF(Dm, Gt[s], 0.0);           // (G~ D)^T
-                        Ms = MF(V1, Gt[s], Mf[s]);                      // G~ D G~^T + M_f   (standard.py:213-216)
-                        o[0] = Ms;
-                        o -= ostride;
+                        Ms = MF(V1, Gt[s], Mf[s]);                      // G~ D G~^T + M_f
+                        if (s + 1 < CHUNK) Dm = Ms - Mp[s + 1];
+                        u32x2 bits;
+                        __builtin_memcpy(&bits, &Ms, 8);
+                        __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, (int)bvoff, (int)((CHUNK - 1 - s) * row_bytes), 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
                     for (int s = 0; s < cnt; ++s) {
