@@ -46,6 +46,10 @@ __device__ __forceinline__ double pair_other(double x) {
     return dpp64_banks<0x124, 0xA>(dpp64_banks<0x12C, 0x5>(x, x), x);
 }
 
+// pair_other for a value that is already the same in the four lanes of every (r, g) quad: row_half_mirror reverses each
+// 8-lane half of a DPP row, lane (g, c) <- (g ^ 1, 3 - c), one move per 32-bit half instead of two moves + a copy
+__device__ __forceinline__ double pair_other_quad_uniform(double x) { return dpp64<0x141>(x); }
+
 // broadcast column 3 of every (r, g) quad to its four lanes
 __device__ __forceinline__ double quad_bcast3(double x) { return dpp64<0xFF>(x); }
 __device__ __forceinline__ double quad_bcast0(double x) { return dpp64<0x00>(x); }

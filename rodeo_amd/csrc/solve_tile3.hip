@@ -65,13 +65,13 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
 
     // per-lane constants in D layout
     const double Qt = in3 ? ld(a.Q, ((size_t)blk * P + c) * P + r, a.Q_b, a.B, b) : ((r == 3 && c == 3) ? 1.0 : 0.0);
+    const double Qt0 = in3 ? Qt : 0.0;                 // Q~^T with the (3,3) one removed: MF(Qt0, U, .) has a zero row 3
     const double Rt = in3 ? ld(a.R, ((size_t)blk * P + r) * P + c, a.R_b, a.B, b) : 0.0;
     const double RtT = in3 ? ld(a.R, ((size_t)blk * P + c) * P + r, a.R_b, a.B, b) : 0.0;   // R~^T
     const double Wr = r < 3 ? ld(a.W, (size_t)blk * P + r, a.W_b, a.B, b) : 0.0;          // W[k] at row k (all columns)
     const double Y0 = r < 3 ? ld(a.Q, ((size_t)blk * P + 0) * P + r, a.Q_b, a.B, b) : 0.0; // Q[0][k] at row k
     const double E0 = r == 0 ? 1.0 : 0.0;                                                  // selects row 0
     const double e3r = r == 3 ? 1.0 : 0.0;
-    const double m3 = r == 3 ? 0.0 : 1.0;
     double th[RHS::NTHETA];
 #pragma unroll
     for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
@@ -82,14 +82,23 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
 
     // M_0 = [0 | ode_init ; 0 1]   (solve.py:53-54)
     double M = r < 3 ? (c == 3 ? ld(a.x0, (size_t)blk * P + r, a.x0_b, a.B, b) : 0.0) : (c == 3 ? 1.0 : 0.0);
-    // lanes without a slot in the 3 x 4 tile (row 3, or tiles past the end) store to this wave's 64-double slice of the
-    // scratch tail of the buffer instead of being masked off: no exec-mask branch in the time loop
+    // lanes without a slot in the 3 x 4 tile: row 3, or tiles past the end
     const bool st = tc.valid && r < 3;
     const size_t tstride_all = (size_t)n_tiles * TILE_DOUBLES;
-    double* out = st ? tiles + (size_t)tc.tau * TILE_DOUBLES + r * 4 + c
-                     : tiles + (size_t)(a.N + 1) * tstride_all + (size_t)blockIdx.x * 64 + threadIdx.x;
-    const size_t tstride = st ? tstride_all : 0;
-    out[0] = M;
+    double* const dump = tiles + (size_t)(a.N + 1) * tstride_all + (size_t)blockIdx.x * 64;
+    dump[threadIdx.x] = r == 3 ? (c == 3 ? 1.0 : 0.0) : 0.0;       // row 3 = e_3 for the backward kernels' slot-less lanes
+    // In the loop every lane stores through a 384-byte buffer window on this wave's part of the time row (scalar base,
+    // no per-lane pointer arithmetic: every VALU instruction lengthens the dependent chain); slot-less lanes are out of
+    // range and dropped by the hardware.
+    const char* row = (const char*)(tiles + (size_t)blockIdx.x * 4 * TILE_DOUBLES);
+    const int bvoff = st ? (int)((tc.g * TILE_DOUBLES + r * 4 + c) * sizeof(double)) : (int)0x80000000;
+    auto store_row = [&](double v) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 4 * TILE_DOUBLES * 8, 0x00020000);
+        u32x2 bits;
+        __builtin_memcpy(&bits, &v, 8);
+        __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, bvoff, 0, 0);
+    };
+    store_row(M);
 
     for (int n = 0; n < a.N; ++n) {
         // ---- predict (standard.py:57-59): U = (Q~ M)^T, M- = Q~ M Q~^T + R~; B0 = row 0 of Q~ M in every row ----
@@ -99,7 +108,9 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         double v_own;                                  // the point the ODE is evaluated at: X[b][0] of this tile's block
         if constexpr (ITG != RK_INTERROGATE_CHKREBTII) v_own = quad_bcast3(MF(Y0, M, 0.0));   // mu-_0 in all 16 lanes
         const double Mp = MF(U, Qt, Rt);
-        const double MpT = MF(Qt, U, RtT);             // exact transpose of M-: Q~ M^T Q~^T + R~^T
+        // exact transpose of M- (Q~ M^T Q~^T + R~^T) with its row 3 (= mu-^T) zeroed, so that the offset entry of X_w
+        // below does not enter Sigma- W~^T
+        const double MpT = MF(Qt0, U, RtT);
         if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
             // interrogate.py:22-34: x ~ N(mu-, Sigma-) with the lower factor; only x_0 = mu-_0 + sqrt(Sigma-_00) z_0
             // reaches f (RHS::NDEP == 1).  The 16 lanes of a tile draw z_0 for 16 consecutive steps at once.
@@ -117,7 +128,7 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
         double fb, J0;
         if constexpr (RHS::HAS_TILE_FORM && D == 2) {
-            RHS::tile_eval(tk, v_own, pair_other(v_own), t, fb, J0);
+            RHS::tile_eval(tk, v_own, pair_other_quad_uniform(v_own), t, fb, J0);    // v_own is uniform in each quad
             if constexpr (ITG != RK_INTERROGATE_KRAMER) J0 = 0.0;
         } else {
             double X[D][P];
@@ -149,14 +160,14 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         const double Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));       // rows: W_0 - J0, W_1, W_2, a
         // ---- update (standard.py:93-102) ----
         const double WS = MF(Xw, Mp, 0.0);                          // [W~ Sigma- | W~ mu- + a]   (column form)
-        const double Z0 = MF(MpT, Xw * m3, 0.0);                    // Sigma- W~^T (standard.py:97; row form, 0 in row 3)
+        const double Z0 = MF(MpT, Xw, 0.0);                         // Sigma- W~^T (standard.py:97; row form, 0 in row 3)
         double S = MF(Z0, Xw, 0.0);
         if constexpr (ITG == RK_INTERROGATE_RODEO || ITG == RK_INTERROGATE_CHKREBTII)
             S = S + S;                                              // var_meas = W Sigma- W^T (interrogate.py:110-113, 26-29)
         const double K = Z0 * fast_rcp(S);
         M = fma(-K, WS, Mp);
-        out += tstride;
-        out[0] = M;
+        row += tstride_all * sizeof(double);
+        store_row(M);
     }
 }
 
