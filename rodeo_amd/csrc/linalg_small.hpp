@@ -19,6 +19,15 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// 1 / x from v_rcp_f64 and ONE cubic step y0 (1 + e + e^2), e = 1 - x y0: three dependent operations instead of the
+// four of two Newton steps, for use on a latency-bound dependent chain.  Error <= 1 ulp like fast_rcp
+// (profiles/r01_probe7_rcp_accuracy.log).
+__device__ __forceinline__ double fast_rcp_cubic(double x) {
+    const double y0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y0, 1.0);
+    return fma(y0, fma(e, e, e), y0);
+}
+
 // C = A (RxK) * B (KxC)
 template <int R, int K, int C>
 __device__ __forceinline__ void mm(const double (&A)[R][K], const double (&B)[K][C], double (&out)[R][C]) {

@@ -48,7 +48,11 @@ __device__ __forceinline__ double pair_other(double x) {
 
 // pair_other for a value that is already the same in the four lanes of every (r, g) quad: row_half_mirror reverses each
 // 8-lane half of a DPP row, lane (g, c) <- (g ^ 1, 3 - c), one move per 32-bit half instead of two moves + a copy
-__device__ __forceinline__ double pair_other_quad_uniform(double x) { return dpp64<0x141>(x); }
+__device__ __forceinline__ double pair_other_quad_uniform(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x141, 0xf, 0xf, false);   // no `old`: every lane has a source
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x141, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 
 // broadcast column 3 of every (r, g) quad to its four lanes
 __device__ __forceinline__ double quad_bcast3(double x) { return dpp64<0xFF>(x); }

@@ -75,8 +75,21 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     double th[RHS::NTHETA];
 #pragma unroll
     for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
-    double tk[6] = {0, 0, 0, 0, 0, 0};
-    if constexpr (RHS::HAS_TILE_FORM && D == 2) RHS::tile_consts(blk, th, tk);
+    // Tile form of the right-hand side (rhs.hpp): f_b = k0 v + k1 v^3 + k2 v' + k3, J_b0 = k4 + k5 v^2 in the block's own
+    // and the other block's first state v, v'.  The measurement row X_w below (W_0 - J0 in row 0, W_r in rows 1 and 2,
+    // the offset a = J0 v - f in row 3) is then ONE cubic per lane with lane-dependent coefficients,
+    //     X_w = ((c3 v + c2) v + c1) v + (co v' + c0),
+    // four fused multiply-adds instead of f, J0, a and two selects (nine): every VALU instruction lengthens the
+    // step's dependent chain.  Same polynomials as interrogate.py:76-82, associated differently at rounding level.
+    double c3 = 0.0, c2 = 0.0, c1 = 0.0, co = 0.0, c0 = Wr;
+    if constexpr (RHS::HAS_TILE_FORM && D == 2) {
+        double tk[6];
+        RHS::tile_consts(blk, th, tk);
+        const bool jac = ITG == RK_INTERROGATE_KRAMER;
+        const double k4 = jac ? tk[4] : 0.0, k5 = jac ? tk[5] : 0.0;
+        if (r == 3) { c3 = k5 - tk[1]; c1 = k4 - tk[0]; co = -tk[2]; c0 = -tk[3]; }
+        if (r == 0) { c2 = -k5; c0 = Wr - k4; }
+    }
     __shared__ double zbuf[4 * 16];                    // chkrebtii: z_0 of the next 16 steps for each of the 4 tiles
     const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
 
@@ -100,6 +113,53 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     };
     store_row(M);
 
+    if constexpr (RHS::HAS_TILE_FORM && D == 2 && ITG != RK_INTERROGATE_CHKREBTII) {
+        // The headline path.  A step is ONE dependent chain for its wave (seven MFMAs, thirteen VALU instructions, one
+        // store), and with few trajectories (at most one wave per SIMD) its latency is the run time.  What was measured
+        // about that chain (profiles/r01_probe2/3/6/8/9*.log): nothing of the same wave overlaps an fp64 MFMA but another,
+        // independent MFMA; a dependent MFMA or any VALU instruction behind an MFMA waits its full 29 cycles; a dependent
+        // VALU operation costs about 7.  Hence: as few instructions as possible (merged cubic for X_w, cubic reciprocal
+        // step, buffer store), and the statement order below, which is the one hipcc's scheduler turns into the
+        // shortest stream (240 cycles per step; its choices for other source orders, and every order pinned with
+        // sched_barriers, measured 250-300).  A loop rotated to take U and the evaluation point off the chain with two
+        // more MFMAs per step measured 344.
+        // The order is pinned with empty asm statements that make an input of the next instruction "depend" on the result
+        // of the previous one: no instruction is emitted, the variables keep their registers, hipcc still inserts the
+        // wait states, and the stream no longer changes with unrelated edits (sched_barriers cost 12-24 cycles per
+        // step; of 220 random valid orders in profiles/r01_probe9_fwd_order_search.log this one was the fastest).
+#define RK_AFTER(in, res) asm("" : "+v"(in) : "v"(res))
+        for (int n = 0; n < a.N; ++n) {
+            double U = MF(M, Qt, 0.0);                              // (Q~ M)^T                         (standard.py:57-59)
+            RK_AFTER(M, U);
+            double B0 = MF(Y0, M, 0.0);                             // row 0 of Q~ M in every row: mu-_0 in column 3
+            RK_AFTER(U, B0);
+            double MpT = MF(Qt0, U, RtT);                           // M-^T with row 3 zeroed: the offset entry of X_w must not enter Z0
+            RK_AFTER(B0, MpT);
+            const double v_own = quad_bcast3(B0);                   // the point the ODE is evaluated at, X[b][0]
+            const double v_oth = pair_other_quad_uniform(v_own);
+            const double Xw = fma(fma(fma(c3, v_own, c2), v_own, c1), v_own, fma(co, v_oth, c0));
+            RK_AFTER(U, Xw);
+            double Mp = MF(U, Qt, Rt);                              // M- = Q~ M Q~^T + R~
+            RK_AFTER(MpT, Mp);
+            double Z0 = MF(MpT, Xw, 0.0);                           // Sigma- W~^T                      (standard.py:97)
+            RK_AFTER(Mp, Z0);
+            double WS = MF(Xw, Mp, 0.0);                            // [W~ Sigma- | W~ mu- + a]
+            RK_AFTER(Z0, WS);
+            double S = MF(Z0, Xw, 0.0);
+            RK_AFTER(WS, S);
+            if constexpr (ITG == RK_INTERROGATE_RODEO) S = S + S;   // var_meas = W Sigma- W^T (interrogate.py:110-113)
+            const double PW = Z0 * WS;
+            RK_AFTER(S, PW);
+            const double y0 = __builtin_amdgcn_rcp(S);
+            const double e = fma(-S, y0, 1.0);
+            const double y = fma(y0, fma(e, e, e), y0);             // 1 / S (linalg_small.hpp, fast_rcp_cubic)
+            M = fma(-PW, y, Mp);                                    // [Sigma- - K (W~ Sigma-) | mu- - K yhat]  (standard.py:98-102)
+            row += tstride_all * sizeof(double);
+            store_row(M);
+        }
+#undef RK_AFTER
+        return;
+    }
     for (int n = 0; n < a.N; ++n) {
         // ---- predict (standard.py:57-59): U = (Q~ M)^T, M- = Q~ M Q~^T + R~; B0 = row 0 of Q~ M in every row ----
         // (a 4x4x4 fp64 MFMA blocks this wave's issue for ~17 cycles = 4 fp64 VALU ops, and nothing overlaps it --
@@ -126,10 +186,10 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         }
         // ---- interrogation (interrogate.py): f and the block-diagonal Jacobian at v_own ----
         const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
-        double fb, J0;
+        double Xw;      // X_w[k] (row form): W~_k = W_k - J_k for k < 3 (solve.py:79, interrogate.py:80), a = -f + J mu- at k = 3
         if constexpr (RHS::HAS_TILE_FORM && D == 2) {
-            RHS::tile_eval(tk, v_own, pair_other_quad_uniform(v_own), t, fb, J0);    // v_own is uniform in each quad
-            if constexpr (ITG != RK_INTERROGATE_KRAMER) J0 = 0.0;
+            const double v_oth = pair_other_quad_uniform(v_own);        // v_own is uniform in each quad
+            Xw = fma(fma(fma(c3, v_own, c2), v_own, c1), v_own, fma(co, v_oth, c0));
         } else {
             double X[D][P];
 #pragma unroll
@@ -152,12 +212,11 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
 #pragma unroll
                     for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
             }
-            fb = f[0]; J0 = J[0][0];
+            double fb = f[0], J0 = J[0][0];
             if constexpr (D == 2) { fb = blk == 0 ? f[0] : f[1]; J0 = blk == 0 ? J[0][0] : J[1][0]; }
+            const double a_meas = fma(J0, v_own, -fb);                  // mean_meas (interrogate.py:81-82)
+            Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));                    // rows: W_0 - J0, W_1, W_2, a
         }
-        // X_w[k] (row form): W~_k = W_k - J_k for k < 3 (solve.py:79, interrogate.py:80), a = -f + J mu- at k = 3
-        const double a_meas = fma(J0, v_own, -fb);                  // mean_meas (interrogate.py:81-82)
-        const double Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));       // rows: W_0 - J0, W_1, W_2, a
         // ---- update (standard.py:93-102) ----
         const double WS = MF(Xw, Mp, 0.0);                          // [W~ Sigma- | W~ mu- + a]   (column form)
         const double Z0 = MF(MpT, Xw, 0.0);                         // Sigma- W~^T (standard.py:97; row form, 0 in row 3)

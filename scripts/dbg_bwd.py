@@ -18,4 +18,12 @@ for B in [int(v) for v in sys.argv[1:]] or [1024]:
             acc.setdefault(k, []).append(ms)
     dev.profile_enable(False)
     print("B =", B, {k: round(float(np.mean(v)), 4) for k, v in acc.items()})
+    dev.profile_enable(True)
+    acc = {}
+    for _ in range(10):
+        plan.filter(None)
+        for k, ms in dev.profile_last():
+            acc.setdefault(k, []).append(ms)
+    dev.profile_enable(False)
+    print("        filter only:", {k: round(float(np.mean(v)), 4) for k, v in acc.items()})
     del plan
