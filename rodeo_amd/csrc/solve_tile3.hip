@@ -17,9 +17,9 @@
 // HBM format ("tile layout"): per time step and tile the 3 x 4 block [Sigma | mu] row-major = 96 B, exactly the
 // algorithmic d*p*(p+1)*8 bytes; a wave's store is 4 x 96 contiguous bytes.
 //
-// Backward (solve.py:279-301): G_n = Sigma_f Q^T (Sigma-)^{-1} does not depend on the carry, so a producer wave
-// evaluates it for 16 time steps x 4 tiles at once (one lane per item, register LU with partial pivoting exactly as the
-// reference's utils.py:119) and hands [M_f | M- | G~^T] tiles to the consumer wave through LDS.  The consumer's
+// Backward (solve.py:279-301): G_n = Sigma_f Q^T (Sigma-)^{-1} does not depend on the carry, so producer waves
+// evaluate it for 16 time steps x 4 tiles at once (one lane per item, register LU with partial pivoting exactly as the
+// reference's utils.py:119) and hand [M_f | M- | G~^T] tiles to the consumer wave through LDS.  The consumer's
 // per-step dependent chain is then  D = Ms - M- ; V1 = MF(D, Gt) = (G~ D)^T ; Ms = MF(V1, Gt, M_f)
 // (standard.py:213-216 for mean and variance at once, G~ = diag(G, 1)).
 #include "common.hpp"
@@ -230,12 +230,12 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     }
 }
 
-// ---- backward: one consumer wave + two producer waves per 4 tiles ----------------------------------------------
-// Time runs in "ticks" separated by workgroup barriers; in tick t the consumer smooths chunk t (16 steps) while
-// the producers prepare later chunks.  Producer q (of three) owns the chunks ch = q (mod 3); its work on chunk ch is
-// split in two phases, A in tick ch-2 (prefetch + predict + T) and B in tick ch-1 (pivoted LU + LDS writes), so in
-// every tick one producer is in phase A, one in phase B and one idle.  Chunk ch is handed over in LDS buffer ch & 1
-// (written during tick ch-1, read during tick ch).
+// ---- backward: one consumer wave + three producer waves per 4 tiles -------------------------------------------------
+// Time runs in "ticks" separated by workgroup barriers; in tick t the consumer smooths chunk t (16 steps) while the
+// producers prepare later chunks.  Producer q (of three) owns the chunks ch = q (mod 3); its work on chunk ch is three
+// stages in the ticks ch-3, ch-2, ch-1 (fetch + predict; T^T and the LU's forward sweep; back substitution + hand-off),
+// so in every tick the three producers each run a different stage of three different chunks.  Chunk ch is handed over
+// in LDS buffer ch & 1 (written during tick ch-1, read during tick ch).
 constexpr int CHUNK = 16;                       // time steps per hand-off
 constexpr int ITEM_BYTES = 3 * 128;              // per (step, tile): M-, G~^T, M_f tiles of 16 doubles
 constexpr int BUF_BYTES = CHUNK * 4 * ITEM_BYTES;   // 24 KiB
