@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
 }
 
 // ---- backward sampler (solve.py:162-204): x_n = mu_f + G (x_{n+1} - mu-) + L~ z_n --------------------------------
-// Everything but the chain in x is carry-independent, so the producers (same two-phase scheme as above) evaluate per
+// Everything but the chain in x is carry-independent, so the producers (same three-stage scheme as above) evaluate per
 // (step, tile): G, mu-, and mu_f + L~ z with L~ = psd_factor(Sigma_f - G T^T) (standard.py:248-254, the draw of
 // solve.py:179) and the Philox normals; the consumer's dependent chain is ONE MFMA per step:
 //     x = MF(G~^T, x - mu-, mu_f + L~ z)        (x, mu-, ... in row form: lane (r, g, c) holds component r)
@@ -464,25 +464,25 @@ __device__ __forceinline__ int sim_vec_byte(int s, int g, int which, int rr) {
     return item * SIM_ITEM + 128 + (vec_slot(s, g, which, rr) << 3);
 }
 
-__global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D) {
+// Same workgroup structure as bwd_mv_tile3_kernel: wave 0 consumes, waves 1..3 produce in three stages per chunk
+// (the Philox normals, the bulk of the producers' work, are split over stages 1 and 2).
+__global__ void __launch_bounds__(256) bwd_sim_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D) {
     constexpr int P = 3;
-    __shared__ __attribute__((aligned(16))) char lds_all[2 * 2 * SIM_BUF];
-    const int wave_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) char lds_all[2 * SIM_BUF];
+    __shared__ __attribute__((aligned(16))) char zones[3 * ZONE_BYTES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * TILE_DOUBLES;
     const int n_chunks = (a.N + CHUNK - 1) / CHUNK;                // steps n = N .. 1 (n = N is the terminal draw)
-    for (int i = threadIdx.x; i < 2 * 2 * SIM_BUF / 8; i += 512) ((double*)lds_all)[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * SIM_BUF / 8; i += 256) ((double*)lds_all)[i] = 0.0;
     __syncthreads();
-    if (wave_id == 4 || wave_id == 5) return;
-    const int grp = wave_id & 1;
-    const int role = wave_id < 2 ? 0 : (wave_id < 4 ? 1 : 2);
-    const int tw = blockIdx.x * 2 + grp;
-    char* const lds_raw = lds_all + grp * 2 * SIM_BUF;
+    const int tw = blockIdx.x;
+    char* const lds_raw = lds_all;
     double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)tw * 64;
 
-    if (role >= 1) {
+    if (wave >= 1) {
         // ---------------- producers ----------------
-        const int p = role - 1;
+        const int p = wave - 1;
         const int s = lane >> 2, g = lane & 3;
         int tau = tw * 4 + g;
         if (tau >= n_tiles) tau = n_tiles - 1;
@@ -490,7 +490,6 @@ __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double*
         const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
         double Q[P][P], R[P][P];
         load_block_consts<P>(a, blk, b, Q, R);
-        const double* tin = tiles + (size_t)tau * TILE_DOUBLES;
         int woff[9], voff[3], voff1[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -499,67 +498,90 @@ __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double*
             voff[i] = sim_vec_byte(s, g, 0, i);
             voff1[i] = sim_vec_byte(s, g, 1, i);
         }
-        double bufE[TILE_DOUBLES], bufO[TILE_DOUBLES];
-        auto fetch = [&](int ch, double (&dst)[TILE_DOUBLES]) {
-            int n = a.N - ch * CHUNK - s;
-            n = n < 1 ? 1 : n;
-            const double* in = tin + (size_t)n * tstride;
+        // LDS-DMA prefetch of the chunk's filt tiles into this wave's landing zone (see bwd_mv_tile3_kernel)
+        char* const zone = zones + p * ZONE_BYTES;
+        const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
+        int frow[6], fcol[6];
 #pragma unroll
-            for (int i = 0; i < TILE_DOUBLES; ++i) dst[i] = in[i];
-        };
-        if (p < n_chunks) fetch(p, bufE);
-        if (p + 2 < n_chunks) fetch(p + 2, bufO);
-        double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P], z[P];
-        auto phaseA = [&](int chA, double (&buf)[TILE_DOUBLES]) {
+        for (int i = 0; i < 6; ++i) { const int j = 64 * i + lane; frow[i] = j / 24; fcol[i] = (j % 24) * 16; }
+        const char* const wave_tiles = (const char*)(tiles + (size_t)tw * 4 * TILE_DOUBLES);
+        auto fetch = [&](int ch) {
+            const int n_hi = a.N - ch * CHUNK;
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-#pragma unroll
-                for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
-                mf[i] = buf[i * 4 + 3];
+            for (int i = 0; i < 6; ++i) {
+                const int n = n_hi - frow[i];
+                lds_dma16(wave_tiles + (size_t)(n < 1 ? 1 : n) * tstride * 8 + fcol[i], zone_lds + 1024 * i);
             }
-            if (chA + 4 < n_chunks) fetch(chA + 4, buf);
-            __builtin_amdgcn_sched_barrier(0);
-            const int n = a.N - chA * CHUNK - s;
-            normals<P>(a.seed, traj, (uint32_t)(n < 1 ? 1 : n), (uint32_t)blk, PURPOSE_SMOOTH, z);
-            predict_block<P>(Q, R, mf, Sf, mp, Sp);
-            mm_nt<P, P, P>(Sf, Q, T);
         };
-        for (int t = -2; t < n_chunks; ++t) {
-            const int chA = t + 2, chB = t + 1;
-            if ((chA & 1) == p) {
-                if (chA < n_chunks) {
-                    if ((chA >> 1) & 1) phaseA(chA, bufO); else phaseA(chA, bufE);
-                }
-            } else if (chB >= 0 && chB < n_chunks) {
-                const int n = a.N - chB * CHUNK - s;
-                double A[P][P], X[P][P], GT[P][P], Ssim[P][P], L[P][P], G[P][P];
+        lds_dma_wait_all();                                        // retire the loads of Q, R before the first DMA
+        if (p < n_chunks) fetch(p);
+        double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P], A[P][P], X[P][P], rpiv[P], z[P];
+        for (int t = -3; t < n_chunks; ++t) {
+            const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
+            if (ch1 % 3 == p) {
+                // ---- stage 1 of chunk ch1: fetched tiles, next fetch, predict, the first two normals ----
+                if (ch1 < n_chunks) {
+                    lds_dma_wait_all();
+                    double buf[TILE_DOUBLES];
 #pragma unroll
-                for (int i = 0; i < P; ++i)
-#pragma unroll
-                    for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
-                lu_solve<P, P>(A, X);                                 // X = G^T   (standard.py:176)
-                const bool term = n == a.N;                           // terminal draw: G = 0, var = filt[N]
-#pragma unroll
-                for (int i = 0; i < P; ++i)
-#pragma unroll
-                    for (int j = 0; j < P; ++j) G[i][j] = term ? 0.0 : X[j][i];
-                mm_nt<P, P, P>(G, T, GT);
-#pragma unroll
-                for (int i = 0; i < P; ++i)
-#pragma unroll
-                    for (int j = 0; j < P; ++j) Ssim[i][j] = Sf[i][j] - GT[i][j];   // standard.py:253-254
-                psd_factor<P>(Ssim, L);
-                if (n >= 1) {
-                    char* o = lds_raw + (chB & 1) * SIM_BUF;
+                    for (int k = 0; k < 6; ++k) {
+                        const double2 v = *(const double2*)(zone + 96 * lane + 16 * k);      // lane = 4 s + g
+                        buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
+                    }
+                    lds_reads_done();
+                    if (ch1 + 3 < n_chunks) fetch(ch1 + 3);
 #pragma unroll
                     for (int i = 0; i < P; ++i) {
-                        double w = mf[i];
 #pragma unroll
-                        for (int k = 0; k <= i; ++k) w = fma(L[i][k], z[k], w);
+                        for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
+                        mf[i] = buf[i * 4 + 3];
+                    }
+                    predict_block<P>(Q, R, mf, Sf, mp, Sp);              // pred[n+1] from filt[n]   (standard.py:57-59)
+                    const int n = a.N - ch1 * CHUNK - s;
+                    normal_pair(a.seed, traj, (uint32_t)(n < 1 ? 1 : n), (uint32_t)blk, PURPOSE_SMOOTH, 0u, z[0], z[1]);
+                }
+            } else if (ch2 >= 0 && ch2 % 3 == p) {
+                // ---- stage 2 of chunk ch2: T (standard.py:175), LU of Sigma- with the forward sweep, the third normal ----
+                if (ch2 < n_chunks) {
+                    mm_nt<P, P, P>(Sf, Q, T);
 #pragma unroll
-                        for (int j = 0; j < P; ++j) *(double*)(o + woff[i * 3 + j]) = G[j][i];      // G~^T
-                        *(double*)(o + voff[i]) = term ? 0.0 : mp[i];
-                        *(double*)(o + voff1[i]) = w;                                               // mu_f + L z
+                    for (int i = 0; i < P; ++i)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
+                    lu_factor_fwd<P, P>(A, X, rpiv);
+                    const int n = a.N - ch2 * CHUNK - s;
+                    double z3;
+                    normal_pair(a.seed, traj, (uint32_t)(n < 1 ? 1 : n), (uint32_t)blk, PURPOSE_SMOOTH, 1u, z[2], z3);
+                }
+            } else if (ch3 >= 0) {
+                // ---- stage 3 of chunk ch3: G (standard.py:176), the conditional draw (standard.py:248-254), hand-off ----
+                if (ch3 < n_chunks) {
+                    const int n = a.N - ch3 * CHUNK - s;
+                    double GT[P][P], Ssim[P][P], L[P][P], G[P][P];
+                    lu_back<P, P>(A, X, rpiv);                            // X = G^T
+                    const bool term = n == a.N;                           // terminal draw: G = 0, var = filt[N]
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) G[i][j] = term ? 0.0 : X[j][i];
+                    mm_nt<P, P, P>(G, T, GT);
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) Ssim[i][j] = Sf[i][j] - GT[i][j];   // standard.py:253-254
+                    psd_factor<P>(Ssim, L);
+                    if (n >= 1) {
+                        char* o = lds_raw + (ch3 & 1) * SIM_BUF;
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+                            double w = mf[i];
+#pragma unroll
+                            for (int k = 0; k <= i; ++k) w = fma(L[i][k], z[k], w);
+#pragma unroll
+                            for (int j = 0; j < P; ++j) *(double*)(o + woff[i * 3 + j]) = G[j][i];      // G~^T
+                            *(double*)(o + voff[i]) = term ? 0.0 : mp[i];
+                            *(double*)(o + voff1[i]) = w;                                               // mu_f + L z
+                        }
                     }
                 }
             }
@@ -582,6 +604,7 @@ __global__ void __launch_bounds__(512) bwd_sim_tile3_kernel(SolveArgs a, double*
             rvec1[k] = sim_vec_byte(k, g, 1, r) - k * 4 * SIM_ITEM;
         }
         double x = 0.0;
+        __syncthreads();
         __syncthreads();
         __syncthreads();
         for (int t = 0; t < n_chunks; ++t) {
@@ -651,7 +674,7 @@ int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     if (rc || mode == RK_MODE_FILTER) return rc;
     if (mode == RK_MODE_SIM) {
         LaunchTimer t(h, "bwd_sim_tile3_kernel");
-        hipLaunchKernelGGL(bwd_sim_tile3_kernel, dim3(div_up(a.B * a.D, 8)), dim3(512), 0, h->stream, a, tiles, a.D);
+        hipLaunchKernelGGL(bwd_sim_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(256), 0, h->stream, a, tiles, a.D);
         t.stop();
         RK_HIP(hipGetLastError());
         return RK_OK;
