@@ -291,6 +291,30 @@ def test_tile_path_equals_batch_minor_path_and_oracle(ra, name, B):
     _vclose(vf, fo["state_filt"][1], 1e-9)
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 15, 16, 17, 18, 33, 49])
+def test_tile_path_short_horizons(ra, N):
+    """
+    Step counts around the backward kernels' 16-step hand-off chunk and three-stage pipeline (no chunk, one partial
+    chunk, exactly one, one + 1, ...), solve_mv and solve_sim through the p = 3 tile kernels, B*d not a multiple of 4.
+    """
+    from rodeo_amd import _lib
+    B = 5
+    s = fitz_problem(ra, N=N, t_max=0.05 * N, sigma=.1, B=B, seed=300 + N)
+    args = (s["W"], s["x0"], 0.0, 0.05 * N, N)
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
+    plan.mv(None)
+    assert plan.layout == _lib.LAYOUT_TILE3
+    m, v = plan.state_host()
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, s["prior"], theta=s["theta"])
+    assert m.shape == mo.shape == (B, N + 1, 2, 3)
+    assert np.max(np.abs(m - mo)) < 1e-10
+    _vclose(v, vo, 1e-9)
+    x = ra.solve_sim(7, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_rodeo, s["prior"], theta=s["theta"])
+    xo = scan.solve_sim(7, odes.fitzhugh_nagumo, *args, oi.interrogate_rodeo, s["prior"], theta=s["theta"])
+    assert x.shape == xo.shape == (B, N + 1, 2, 3)
+    assert np.max(np.abs(x - xo)) < 1e-8
+
+
 def test_tile_path_higher_order_single_block(ra):
     """n_block = 1 through the tile path (4 trajectories per wave), p = 3: x'' = sin 2t - x with W = [0, 0, 1]."""
     from rodeo_amd import _lib
