@@ -29,50 +29,63 @@ struct DenseArgs {
 
 constexpr int DT = 256;
 
-// C (M x N, ldc) = ce * E + cab * op(A) op(B); op = transpose if TA / TB.  Row-major, global memory, the whole
-// workgroup cooperates: thread (ty, tx) of a 16 x 16 grid owns the 4 x 4 micro-tile {ty + 16 a} x {tx + 16 b} of each
-// 64 x 64 block of C.  E may alias C (each element is read and written by the same thread).
+// C (M x N, ldc) = ce * E + cab * op(A) op(B); op = transpose if TA / TB.  Row-major, global memory (the per-trajectory
+// working set lives in L2 / the Infinity Cache), the whole workgroup cooperates: each wave takes 32 x 32 blocks of C and
+// accumulates them with v_mfma_f64_16x16x4_f64 -- four accumulators, two A and two B fragments per 4-deep k step, one
+// 8-byte load per lane per MFMA.  E may alias C (each element is read and written by the same lane).
+// Fragment layout (profiles/r01_probe10_mfma_f64_16x16x4.log): A lane = 16 k + i, B lane = 16 k + j,
+// D[i][j] in lane 16 (i % 4) + j, register i / 4; one MFMA = 64 cycles = the SIMD's fp64 peak, also with a single
+// accumulator chain.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
 template <bool TA, bool TB>
 __device__ void wg_gemm(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
                         const double* E, int lde, double ce, double cab) {
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    for (int bi = 0; bi < M; bi += 64)
-        for (int bj = 0; bj < N; bj += 64) {
-            int ia[4], jb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ia[q] = min(bi + ty + 16 * q, M - 1);
-                jb[q] = min(bj + tx + 16 * q, N - 1);
-            }
-            double acc[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-            for (int k = 0; k < K; ++k) {
-                double av[4], bv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    av[q] = TA ? A[(size_t)k * lda + ia[q]] : A[(size_t)ia[q] * lda + k];
-                    bv[q] = TB ? B[(size_t)jb[q] * ldb + k] : B[(size_t)k * ldb + jb[q]];
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int i = bi + ty + 16 * a, j = bj + tx + 16 * b;
-                    if (i < M && j < N) {
-                        double v = cab * acc[a][b];
-                        if (E) v = fma(ce, E[(size_t)i * lde + j], v);
-                        C[(size_t)i * ldc + j] = v;
-                    }
-                }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = DT / 64;
+    const int lo = lane & 15, hi = lane >> 4;                    // fragment coordinates: (i or j, k)
+    const int tiles_n = (N + 31) / 32, n_tiles = ((M + 31) / 32) * tiles_n;
+    for (int tile = wave; tile < n_tiles; tile += n_waves) {
+        const int bi = (tile / tiles_n) * 32, bj = (tile % tiles_n) * 32;
+        // per-lane row / column of the two A and two B fragments (clamped; out-of-range ones are zeroed)
+        const int i0 = bi + lo, i1 = bi + 16 + lo, j0 = bj + lo, j1 = bj + 16 + lo;
+        const bool vi0 = i0 < M, vi1 = i1 < M, vj0 = j0 < N, vj1 = j1 < N;
+        const int ci0 = vi0 ? i0 : M - 1, ci1 = vi1 ? i1 : M - 1, cj0 = vj0 ? j0 : N - 1, cj1 = vj1 ? j1 : N - 1;
+        auto ldA = [&](int ci, bool ok, int k) -> double {
+            const bool okk = ok && k < K;
+            const int kk = k < K ? k : K - 1;
+            const double v = TA ? A[(size_t)kk * lda + ci] : A[(size_t)ci * lda + kk];
+            return okk ? v : 0.0;
+        };
+        auto ldB = [&](int cj, bool ok, int k) -> double {
+            const bool okk = ok && k < K;
+            const int kk = k < K ? k : K - 1;
+            const double v = TB ? B[(size_t)cj * ldb + kk] : B[(size_t)kk * ldb + cj];
+            return okk ? v : 0.0;
+        };
+        d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+        double a0 = ldA(ci0, vi0, hi), a1 = ldA(ci1, vi1, hi), b0 = ldB(cj0, vj0, hi), b1 = ldB(cj1, vj1, hi);
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int kn = k0 + 4 + hi;                              // next step's fragments (zero past K)
+            const double na0 = ldA(ci0, vi0, kn), na1 = ldA(ci1, vi1, kn), nb0 = ldB(cj0, vj0, kn), nb1 = ldB(cj1, vj1, kn);
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11, 0, 0, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
+        auto put = [&](const d4& acc, int ib, int jb) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = ib + 4 * v + hi, j = jb + lo;
+                if (i < M && j < N) {
+                    double x = cab * acc[v];
+                    if (E) x = fma(ce, E[(size_t)i * lde + j], x);
+                    C[(size_t)i * ldc + j] = x;
+                }
+            }
+        };
+        put(acc00, bi, bj); put(acc01, bi, bj + 16); put(acc10, bi + 16, bj); put(acc11, bi + 16, bj + 16);
+    }
     __syncthreads();
 }
 
@@ -92,7 +105,7 @@ __device__ void wg_gemv(double* y, const double* A, int lda, const double* x, in
 
 // In-place LU with partial pivoting of A (n x n, lda) -- first maximum of |a_ik| like LAPACK getrf -- then
 // X = A^{-1} Bm for the nr right-hand-side columns of Bm (n x nr, ldb), overwritten.  piv: n ints in global memory.
-__device__ void wg_lu_solve(double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
+__device__ void wg_lu_solve_unblocked(double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
     __shared__ double red_v[DT];
     __shared__ int red_i[DT];
     for (int k = 0; k < n; ++k) {
@@ -159,6 +172,135 @@ __device__ void wg_lu_solve(double* A, int lda, double* Bm, int ldb, int n, int 
         }
     }
     __syncthreads();
+}
+
+// Blocked version of the above (right-looking, panels of 16 columns factored in LDS, trailing updates and the
+// right-hand sides' block updates by wg_gemm on the MFMA): same pivots (first maximum of |a_ik|, LAPACK getrf) and the
+// same L, U up to the order of summation.  The triangular solves with the 16 x 16 diagonal blocks run one thread per
+// column; divisions by the pivots are multiplications with their reciprocals (as getf2 scales its columns).
+constexpr int LU_NB = 16, LU_MAXN = 320, LU_LD = LU_NB + 1;
+
+__device__ void wg_lu_solve(double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
+    if (n > LU_MAXN) { wg_lu_solve_unblocked(A, lda, Bm, ldb, n, nr, piv); return; }
+    __shared__ double panel[LU_MAXN * LU_LD];          // rows k0.. of the current panel, row stride 17 (bank spread)
+    __shared__ double red_v[DT / 64];
+    __shared__ int red_i[DT / 64];
+    __shared__ int ppiv[LU_NB];
+    __shared__ double rdiag[LU_NB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k0 = 0; k0 < n; k0 += LU_NB) {
+        const int nb = min(LU_NB, n - k0), rows = n - k0;
+        for (int e = tid; e < rows * nb; e += DT) panel[(e / nb) * LU_LD + e % nb] = A[(size_t)(k0 + e / nb) * lda + k0 + e % nb];
+        __syncthreads();
+        for (int j = 0; j < nb; ++j) {
+            // pivot search in panel column j, rows j..rows-1: first maximum
+            double best = -1.0;
+            int bi = j;
+            for (int r = j + tid; r < rows; r += DT) {
+                const double v = fabs(panel[r * LU_LD + j]);
+                if (v > best) { best = v; bi = r; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double v2 = __shfl_xor(best, off);
+                const int i2 = __shfl_xor(bi, off);
+                if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+            }
+            if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
+            __syncthreads();
+            best = red_v[0]; bi = red_i[0];
+#pragma unroll
+            for (int w = 1; w < DT / 64; ++w) {
+                const double v2 = red_v[w];
+                const int i2 = red_i[w];
+                if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+            }
+            const int pj = bi;
+            if (tid < nb && pj != j) {
+                const double t = panel[j * LU_LD + tid];
+                panel[j * LU_LD + tid] = panel[pj * LU_LD + tid];
+                panel[pj * LU_LD + tid] = t;
+            }
+            if (tid == 0) ppiv[j] = k0 + pj;
+            __syncthreads();
+            const double rinv = 1.0 / panel[j * LU_LD + j];
+            for (int r = j + 1 + tid; r < rows; r += DT) {
+                const double l = panel[r * LU_LD + j] * rinv;
+                panel[r * LU_LD + j] = l;
+                for (int c = j + 1; c < nb; ++c) panel[r * LU_LD + c] = fma(-l, panel[j * LU_LD + c], panel[r * LU_LD + c]);
+            }
+            __syncthreads();
+        }
+        // panel back to A; pivots; row interchanges on the other columns of A and on the right-hand sides
+        for (int e = tid; e < rows * nb; e += DT) A[(size_t)(k0 + e / nb) * lda + k0 + e % nb] = panel[(e / nb) * LU_LD + e % nb];
+        if (tid < nb) piv[k0 + tid] = ppiv[tid];
+        const int n_other = n - nb;
+        for (int cc = tid; cc < n_other + nr; cc += DT) {
+            double* col;
+            int ld;
+            if (cc < n_other) { col = A + (cc < k0 ? cc : cc + nb); ld = lda; } else { col = Bm + (cc - n_other); ld = ldb; }
+            for (int j = 0; j < nb; ++j) {
+                const int pk = ppiv[j];
+                if (pk != k0 + j) {
+                    const double t = col[(size_t)(k0 + j) * ld];
+                    col[(size_t)(k0 + j) * ld] = col[(size_t)pk * ld];
+                    col[(size_t)pk * ld] = t;
+                }
+            }
+        }
+        __syncthreads();
+        // U12 = L11^{-1} A12 and B1 = L11^{-1} B1 (unit lower triangle from the panel), one thread per column
+        const int n_right = n - k0 - nb;
+        for (int cc = tid; cc < n_right + nr; cc += DT) {
+            double* col;
+            int ld;
+            if (cc < n_right) { col = A + k0 + nb + cc; ld = lda; } else { col = Bm + (cc - n_right); ld = ldb; }
+            double x[LU_NB];                               // constant trip counts: x stays in registers
+#pragma unroll
+            for (int j = 0; j < LU_NB; ++j) {
+                double sacc = j < nb ? col[(size_t)(k0 + j) * ld] : 0.0;
+#pragma unroll
+                for (int i = 0; i < j; ++i) sacc = fma(-panel[j * LU_LD + i], x[i], sacc);
+                x[j] = sacc;
+            }
+#pragma unroll
+            for (int j = 0; j < LU_NB; ++j)
+                if (j < nb) col[(size_t)(k0 + j) * ld] = x[j];
+        }
+        __syncthreads();
+        if (n_right > 0) {
+            double* L21 = A + (size_t)(k0 + nb) * lda + k0;
+            double* A22 = A + (size_t)(k0 + nb) * lda + k0 + nb;
+            wg_gemm<false, false>(A22, lda, L21, lda, A + (size_t)k0 * lda + k0 + nb, lda, n_right, n_right, nb, A22, lda, 1.0, -1.0);
+            double* B2 = Bm + (size_t)(k0 + nb) * ldb;
+            wg_gemm<false, false>(B2, ldb, L21, lda, Bm + (size_t)k0 * ldb, ldb, n_right, nr, nb, B2, ldb, 1.0, -1.0);
+        }
+    }
+    // back substitution with U, block rows from the bottom
+    for (int k0 = ((n - 1) / LU_NB) * LU_NB; k0 >= 0; k0 -= LU_NB) {
+        const int nb = min(LU_NB, n - k0);
+        for (int e = tid; e < nb * nb; e += DT) panel[(e / nb) * LU_LD + e % nb] = A[(size_t)(k0 + e / nb) * lda + k0 + e % nb];
+        __syncthreads();
+        if (tid < nb) rdiag[tid] = 1.0 / panel[tid * LU_LD + tid];
+        __syncthreads();
+        for (int c = tid; c < nr; c += DT) {
+            double x[LU_NB];
+#pragma unroll
+            for (int j = LU_NB - 1; j >= 0; --j) {
+                double sacc = j < nb ? Bm[(size_t)(k0 + j) * ldb + c] : 0.0;
+#pragma unroll
+                for (int i = j + 1; i < LU_NB; ++i)
+                    if (i < nb) sacc = fma(-panel[j * LU_LD + i], x[i], sacc);
+                x[j] = j < nb ? sacc * rdiag[j] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < LU_NB; ++j)
+                if (j < nb) Bm[(size_t)(k0 + j) * ldb + c] = x[j];
+        }
+        __syncthreads();
+        if (k0 > 0)
+            wg_gemm<false, false>(Bm, ldb, A + k0, lda, Bm + (size_t)k0 * ldb, ldb, k0, nr, nb, Bm, ldb, 1.0, -1.0);
+    }
 }
 
 struct DenseWs {
