@@ -8,9 +8,12 @@
 // Layout: trajectory-major = the reference's own layout with a leading batch axis:
 //   mean (B, N+1, p), var (B, N+1, p, p)  (n_block = 1), so a workgroup streams contiguous p x p matrices.
 //
-// First version: correct and roofline-aware but not tuned -- the GEMMs are VALU register-tiled (4 x 4 per thread),
-// the LU is unblocked.  (On MI355X the fp64 MFMA peak equals the fp64 VALU peak; MFMA's gain here is 4x fewer
-// operand loads, which is the next step for this path.)
+// GEMMs: v_mfma_f64_16x16x4_f64 with op(B) staged through LDS (wg_gemm); LU: blocked, panels of 16 columns in LDS,
+// trailing and right-hand-side updates through wg_gemm.  Measured on C5 (B = 256, p = 160, m = 32): 8.9 % of the fp64
+// peak on the reference algorithm's flop count; what remains is the panel factorisation's barrier chain and the
+// thread-per-column triangular solves / row interchanges (a register-row panel variant was tried and was not faster).
+// Every helper is force-inlined: with real calls the 400+ VGPR frames made hipcc's callee-saved spills fault at run
+// time (found the hard way).
 #include "common.hpp"
 #include "linalg_small.hpp"
 #include "solve_args.hpp"
@@ -29,69 +32,147 @@ struct DenseArgs {
 
 constexpr int DT = 256;
 
-// C (M x N, ldc) = ce * E + cab * op(A) op(B); op = transpose if TA / TB.  Row-major, global memory (the per-trajectory
-// working set lives in L2 / the Infinity Cache), the whole workgroup cooperates: each wave takes 32 x 32 blocks of C and
-// accumulates them with v_mfma_f64_16x16x4_f64 -- four accumulators, two A and two B fragments per 4-deep k step, one
-// 8-byte load per lane per MFMA.  E may alias C (each element is read and written by the same lane).
+// C (M x N, ldc) = ce * E + cab * op(A) op(B); op = transpose if TA / TB.  Row-major operands in global memory; the
+// whole workgroup cooperates.  op(B) is staged through LDS in column chunks of up to 80 (K x 80 doubles = 100 KiB at
+// K = 160), each wave takes 16-row blocks of C and accumulates a block row of the chunk (up to five 16 x 16 tiles) with
+// v_mfma_f64_16x16x4_f64: per 4-deep k step ONE 8-byte global load per lane (the A fragment, prefetched four steps
+// ahead) feeds five MFMAs whose B fragments come from LDS.  So op(B) is read from memory once and A once per chunk
+// (twice at N = 160) -- the first version (32 x 32 tiles straight from memory, every operand re-read five times) was
+// bound by the 1 MB/trajectory working set streaming from HBM: 330k cycles per 160^3 product against 64k of MFMA time.
+// E may alias C (each element is read and written by the same lane).
 // Fragment layout (profiles/r01_probe10_mfma_f64_16x16x4.log): A lane = 16 k + i, B lane = 16 k + j,
 // D[i][j] in lane 16 (i % 4) + j, register i / 4; one MFMA = 64 cycles = the SIMD's fp64 peak, also with a single
 // accumulator chain.
 typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int GEMM_LDS_DOUBLES = 12800;          // 100 KiB, shared with the LU panel
+constexpr int GEMM_MAX_NC = 80;
+
+// One wave's 16-row block of C against the staged chunk (NT tiles of 16 columns): the k loop.  A fragments are loaded
+// PF steps ahead with clamped indices and NO select behind the load (a select would make hipcc wait for the load at
+// once): rows past M are never stored, and columns past K meet the zero rows of the staged op(B).
+template <bool TA, int NT>
+__device__ __forceinline__ void gemm_row_block(const double* lds, int NCP, int Kp, double* C, int ldc, const double* A, int lda,
+                                               int M, int N, int K, const double* E, int lde, double ce, double cab,
+                                               int ib, int jc) {
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    const int ci = min(ib + lo, M - 1);
+    const double* arow = TA ? A + ci : A + (size_t)ci * lda;
+    const size_t astep = TA ? (size_t)lda : 1;                    // address step per k
+    auto ldA = [&](int k) -> double { return arow[(size_t)min(k, K - 1) * astep]; };
+    constexpr int PF = 4;
+    double fa[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) fa[q] = ldA(4 * q + hi);
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = d4{0, 0, 0, 0};
+    const double* brow = lds + hi * NCP + lo;
+    double bc[NT];                                                // B fragments, read from LDS one k step ahead
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bc[t] = brow[16 * t];
+    for (int k0 = 0; k0 < Kp; k0 += 4 * PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int kq = k0 + 4 * q;
+            if (kq < Kp) {
+                const double a = fa[q];
+                fa[q] = ldA(kq + 4 * PF + hi);
+                double bn[NT];
+                const int kn = min(kq + 4, Kp - 4);                 // (the last step re-reads its own rows)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bn[t] = brow[kn * NCP + 16 * t];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bc[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bc[t] = bn[t];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ii = ib + 4 * v + hi, j = jc + 16 * t + lo;
+            if (ii < M && j < N) {
+                double x = cab * acc[t][v];
+                if (E) x = fma(ce, E[(size_t)ii * lde + j], x);
+                C[(size_t)ii * ldc + j] = x;
+            }
+        }
+    }
+}
 
 template <bool TA, bool TB>
-__device__ void wg_gemm(double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int N, int K,
-                        const double* E, int lde, double ce, double cab) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = DT / 64;
-    const int lo = lane & 15, hi = lane >> 4;                    // fragment coordinates: (i or j, k)
-    const int tiles_n = (N + 31) / 32, n_tiles = ((M + 31) / 32) * tiles_n;
-    for (int tile = wave; tile < n_tiles; tile += n_waves) {
-        const int bi = (tile / tiles_n) * 32, bj = (tile % tiles_n) * 32;
-        // per-lane row / column of the two A and two B fragments (clamped; out-of-range ones are zeroed)
-        const int i0 = bi + lo, i1 = bi + 16 + lo, j0 = bj + lo, j1 = bj + 16 + lo;
-        const bool vi0 = i0 < M, vi1 = i1 < M, vj0 = j0 < N, vj1 = j1 < N;
-        const int ci0 = vi0 ? i0 : M - 1, ci1 = vi1 ? i1 : M - 1, cj0 = vj0 ? j0 : N - 1, cj1 = vj1 ? j1 : N - 1;
-        auto ldA = [&](int ci, bool ok, int k) -> double {
-            const bool okk = ok && k < K;
-            const int kk = k < K ? k : K - 1;
-            const double v = TA ? A[(size_t)kk * lda + ci] : A[(size_t)ci * lda + kk];
-            return okk ? v : 0.0;
-        };
-        auto ldB = [&](int cj, bool ok, int k) -> double {
-            const bool okk = ok && k < K;
-            const int kk = k < K ? k : K - 1;
-            const double v = TB ? B[(size_t)cj * ldb + kk] : B[(size_t)kk * ldb + cj];
-            return okk ? v : 0.0;
-        };
-        d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-        double a0 = ldA(ci0, vi0, hi), a1 = ldA(ci1, vi1, hi), b0 = ldB(cj0, vj0, hi), b1 = ldB(cj1, vj1, hi);
-        for (int k0 = 0; k0 < K; k0 += 4) {
-            const int kn = k0 + 4 + hi;                              // next step's fragments (zero past K)
-            const double na0 = ldA(ci0, vi0, kn), na1 = ldA(ci1, vi1, kn), nb0 = ldB(cj0, vj0, kn), nb1 = ldB(cj1, vj1, kn);
-            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11, 0, 0, 0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-        }
-        auto put = [&](const d4& acc, int ib, int jb) {
+__device__ __forceinline__ void wg_gemm(double* lds, double* C, int ldc, const double* A, int lda, const double* B, int ldb,
+                                        int M, int N, int K, const double* E, int lde, double ce, double cab) {
+    const int wave = threadIdx.x >> 6, n_waves = DT / 64;
+    const int Kp = (K + 3) & ~3;
+    int NC = min(GEMM_MAX_NC, GEMM_LDS_DOUBLES / Kp / 16 * 16);  // chunk width (multiple of 16; K <= 768: dense_check)
+    if (NC > ((N + 15) & ~15)) NC = (N + 15) & ~15;
+    if (NC % 32 == 0 && Kp * (NC + 16) > GEMM_LDS_DOUBLES) NC -= 16;
+    const int NCP = (NC % 32 == 0) ? NC + 16 : NC;               // row stride = 16 (mod 32) doubles: the fragment's four k rows
+                                                                 // fall into alternating halves of the 64 banks
+    for (int jc = 0; jc < N; jc += NC) {
+        const int nc = min(NC, N - jc), n_tile = (nc + 15) >> 4;
+        // stage op(B)[0:Kp, jc:jc + 16 n_tile) (zero outside K x nc): threads as a 16 x 16 grid, 128 contiguous bytes per
+        // row of 16 threads, up to 2 x 5 independent loads in flight per thread
+        {
+            const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+            if (TB) {
+                for (int k1 = 0; k1 < Kp; k1 += 32) {
+                    double v[2][GEMM_MAX_NC / 16];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int i = ib + 4 * v + hi, j = jb + lo;
-                if (i < M && j < N) {
-                    double x = cab * acc[v];
-                    if (E) x = fma(ce, E[(size_t)i * lde + j], x);
-                    C[(size_t)i * ldc + j] = x;
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int t = 0; t < GEMM_MAX_NC / 16; ++t) {
+                            const int k = k1 + 16 * r + tx, j = 16 * t + ty;
+                            v[r][t] = (t < n_tile && k < K && j < nc) ? B[(size_t)(jc + j) * ldb + k] : 0.0;
+                        }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int t = 0; t < GEMM_MAX_NC / 16; ++t) {
+                            const int k = k1 + 16 * r + tx, j = 16 * t + ty;
+                            if (t < n_tile && k < Kp) lds[k * NCP + j] = v[r][t];
+                        }
+                }
+            } else {
+                for (int k1 = 0; k1 < Kp; k1 += 32) {
+                    double v[2][GEMM_MAX_NC / 16];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int t = 0; t < GEMM_MAX_NC / 16; ++t) {
+                            const int k = k1 + 16 * r + ty, j = 16 * t + tx;
+                            v[r][t] = (t < n_tile && k < K && j < nc) ? B[(size_t)k * ldb + jc + j] : 0.0;
+                        }
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int t = 0; t < GEMM_MAX_NC / 16; ++t) {
+                            const int k = k1 + 16 * r + ty, j = 16 * t + tx;
+                            if (t < n_tile && k < Kp) lds[k * NCP + j] = v[r][t];
+                        }
                 }
             }
-        };
-        put(acc00, bi, bj); put(acc01, bi, bj + 16); put(acc10, bi + 16, bj); put(acc11, bi + 16, bj + 16);
+        }
+        __syncthreads();
+        for (int ib = wave * 16; ib < M; ib += n_waves * 16) {
+            switch (n_tile) {           // compile-time tile count: no branches inside the k loop
+                case 1: gemm_row_block<TA, 1>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
+                case 2: gemm_row_block<TA, 2>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
+                case 3: gemm_row_block<TA, 3>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
+                case 4: gemm_row_block<TA, 4>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
+                default: gemm_row_block<TA, 5>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // y (M) = ce * e + cab * op(A) x ; A (M x K) or, if TA, A is (K x M) and op(A) = A^T
 template <bool TA>
-__device__ void wg_gemv(double* y, const double* A, int lda, const double* x, int M, int K, const double* e,
+__device__ __forceinline__ void wg_gemv(double* y, const double* A, int lda, const double* x, int M, int K, const double* e,
                         double ce, double cab) {
     for (int i = threadIdx.x; i < M; i += DT) {
         double s = 0.0;
@@ -105,7 +186,7 @@ __device__ void wg_gemv(double* y, const double* A, int lda, const double* x, in
 
 // In-place LU with partial pivoting of A (n x n, lda) -- first maximum of |a_ik| like LAPACK getrf -- then
 // X = A^{-1} Bm for the nr right-hand-side columns of Bm (n x nr, ldb), overwritten.  piv: n ints in global memory.
-__device__ void wg_lu_solve_unblocked(double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
+__device__ __noinline__ void wg_lu_solve_unblocked(double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
     __shared__ double red_v[DT];
     __shared__ int red_i[DT];
     for (int k = 0; k < n; ++k) {
@@ -180,9 +261,10 @@ __device__ void wg_lu_solve_unblocked(double* A, int lda, double* Bm, int ldb, i
 // column; divisions by the pivots are multiplications with their reciprocals (as getf2 scales its columns).
 constexpr int LU_NB = 16, LU_MAXN = 320, LU_LD = LU_NB + 1;
 
-__device__ void wg_lu_solve(double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
+__device__ __forceinline__ void wg_lu_solve(double* lds, double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
     if (n > LU_MAXN) { wg_lu_solve_unblocked(A, lda, Bm, ldb, n, nr, piv); return; }
-    __shared__ double panel[LU_MAXN * LU_LD];          // rows k0.. of the current panel, row stride 17 (bank spread)
+    double* const panel = lds;                         // rows k0.. of the current panel, row stride 17 (bank spread); the
+                                                       // buffer is free again whenever a wg_gemm is called
     __shared__ double red_v[DT / 64];
     __shared__ int red_i[DT / 64];
     __shared__ int ppiv[LU_NB];
@@ -271,9 +353,9 @@ __device__ void wg_lu_solve(double* A, int lda, double* Bm, int ldb, int n, int 
         if (n_right > 0) {
             double* L21 = A + (size_t)(k0 + nb) * lda + k0;
             double* A22 = A + (size_t)(k0 + nb) * lda + k0 + nb;
-            wg_gemm<false, false>(A22, lda, L21, lda, A + (size_t)k0 * lda + k0 + nb, lda, n_right, n_right, nb, A22, lda, 1.0, -1.0);
+            wg_gemm<false, false>(lds, A22, lda, L21, lda, A + (size_t)k0 * lda + k0 + nb, lda, n_right, n_right, nb, A22, lda, 1.0, -1.0);
             double* B2 = Bm + (size_t)(k0 + nb) * ldb;
-            wg_gemm<false, false>(B2, ldb, L21, lda, Bm + (size_t)k0 * ldb, ldb, n_right, nr, nb, B2, ldb, 1.0, -1.0);
+            wg_gemm<false, false>(lds, B2, ldb, L21, lda, Bm + (size_t)k0 * ldb, ldb, n_right, nr, nb, B2, ldb, 1.0, -1.0);
         }
     }
     // back substitution with U, block rows from the bottom
@@ -299,7 +381,7 @@ __device__ void wg_lu_solve(double* A, int lda, double* Bm, int ldb, int n, int 
         }
         __syncthreads();
         if (k0 > 0)
-            wg_gemm<false, false>(Bm, ldb, A + k0, lda, Bm + (size_t)k0 * ldb, ldb, k0, nr, nb, Bm, ldb, 1.0, -1.0);
+            wg_gemm<false, false>(lds, Bm, ldb, A + k0, lda, Bm + (size_t)k0 * ldb, ldb, k0, nr, nb, Bm, ldb, 1.0, -1.0);
     }
 }
 
@@ -308,7 +390,7 @@ struct DenseWs {
     int* piv;
 };
 
-__device__ DenseWs carve(double* w, int p, int m) {
+__device__ __forceinline__ DenseWs carve(double* w, int p, int m) {
     DenseWs d;
     const size_t pp = (size_t)p * p, mp = (size_t)m * p;
     d.A1 = w; d.A2 = d.A1 + pp; d.A3 = d.A2 + pp; d.A4 = d.A3 + pp;
@@ -323,14 +405,15 @@ size_t dense_ws_doubles(int p, int m) {
 }
 
 // predicted moments from (mu, Sigma): A1 = Q Sigma, A2 = A1 Q^T + R, mup = Q mu      (standard.py:57-59)
-__device__ void dense_predict(const DenseArgs& a, const DenseWs& w, const double* mu, const double* Sig) {
+__device__ __forceinline__ void dense_predict(double* lds, const DenseArgs& a, const DenseWs& w, const double* mu, const double* Sig) {
     const int p = a.p;
-    wg_gemm<false, false>(w.A1, p, a.Q, p, Sig, p, p, p, p, nullptr, 0, 0.0, 1.0);
-    wg_gemm<false, true>(w.A2, p, w.A1, p, a.Q, p, p, p, p, a.R, p, 1.0, 1.0);
+    wg_gemm<false, false>(lds, w.A1, p, a.Q, p, Sig, p, p, p, p, nullptr, 0, 0.0, 1.0);
+    wg_gemm<false, true>(lds, w.A2, p, w.A1, p, a.Q, p, p, p, p, a.R, p, 1.0, 1.0);
     wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
 }
 
 __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[GEMM_LDS_DOUBLES];
     const int b = blockIdx.x, p = a.p, m = a.m;
     const int nd = p / m;                              // derivatives per variable: x_v = X[v * nd]
     const DenseWs w = carve(a.ws + (size_t)b * a.ws_stride, p, m);
@@ -346,7 +429,7 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
         const double* Sig = var + (size_t)n * p * p;
         double* mu_o = mean + (size_t)(n + 1) * p;
         double* Sig_o = var + (size_t)(n + 1) * p * p;
-        dense_predict(a, w, mu, Sig);
+        dense_predict(lds, a, w, mu, Sig);
         // ---- interrogation (interrogate.py) for the linear ODE f = A x, x_v = X[v * nd] ----
         for (int i = threadIdx.x; i < m; i += DT) {
             double s = 0.0;
@@ -377,24 +460,25 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
             w.yhat[i] = wm + am;                                         // standard.py:93
         }
         // ---- update (standard.py:93-102) ----
-        wg_gemm<false, false>(w.WS, p, w.Wt, p, w.A2, p, m, p, p, nullptr, 0, 0.0, 1.0);          // W~ Sigma-
-        wg_gemm<false, true>(w.S, m, w.WS, p, w.Wt, p, m, m, p, nullptr, 0, 0.0, 1.0);            // (W~ Sigma-) W~^T
+        wg_gemm<false, false>(lds, w.WS, p, w.Wt, p, w.A2, p, m, p, p, nullptr, 0, 0.0, 1.0);          // W~ Sigma-
+        wg_gemm<false, true>(lds, w.S, m, w.WS, p, w.Wt, p, m, m, p, nullptr, 0, 0.0, 1.0);            // (W~ Sigma-) W~^T
         if (a.itg == RK_INTERROGATE_RODEO) {                              // + var_meas = W Sigma- W^T (W~ = W)
             for (int e = threadIdx.x; e < m * m; e += DT) w.S[e] = w.S[e] + w.S[e];
             __syncthreads();
         }
-        wg_gemm<false, true>(w.X, p, w.Wt, p, w.A2, p, m, p, p, nullptr, 0, 0.0, 1.0);            // (Sigma- W~^T)^T
-        wg_lu_solve(w.S, m, w.X, p, m, p, w.piv);                                                  // X = K^T (utils.py:119)
+        wg_gemm<false, true>(lds, w.X, p, w.Wt, p, w.A2, p, m, p, p, nullptr, 0, 0.0, 1.0);            // (Sigma- W~^T)^T
+        wg_lu_solve(lds, w.S, m, w.X, p, m, p, w.piv);                                                  // X = K^T (utils.py:119)
         for (int i = threadIdx.x; i < p; i += DT) {
             double s = 0.0;
             for (int j = 0; j < m; ++j) s = fma(w.X[(size_t)j * p + i], 0.0 - w.yhat[j], s);
             mu_o[i] = w.mup[i] + s;                                      // standard.py:99-100 with x_meas = 0
         }
-        wg_gemm<true, false>(Sig_o, p, w.X, p, w.WS, p, p, p, m, w.A2, p, 1.0, -1.0);             // Sigma- - K (W~ Sigma-)
+        wg_gemm<true, false>(lds, Sig_o, p, w.X, p, w.WS, p, p, p, m, w.A2, p, 1.0, -1.0);             // Sigma- - K (W~ Sigma-)
     }
 }
 
 __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[GEMM_LDS_DOUBLES];
     const int b = blockIdx.x, p = a.p, m = a.m;
     const DenseWs w = carve(a.ws + (size_t)b * a.ws_stride, p, m);
     double* mean = a.mean + (size_t)b * (a.N + 1) * p;
@@ -404,20 +488,20 @@ __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
         double* Sig_f = var + (size_t)n * p * p;
         const double* mu_s = mean + (size_t)(n + 1) * p;           // already smoothed (in place)
         const double* Sig_s = var + (size_t)(n + 1) * p * p;
-        dense_predict(a, w, mu_f, Sig_f);                          // pred[n+1] re-evaluated from filt[n]
-        wg_gemm<false, true>(w.A3, p, a.Q, p, Sig_f, p, p, p, p, nullptr, 0, 0.0, 1.0);   // T^T = Q Sigma_f^T (standard.py:175)
+        dense_predict(lds, a, w, mu_f, Sig_f);                          // pred[n+1] re-evaluated from filt[n]
+        wg_gemm<false, true>(lds, w.A3, p, a.Q, p, Sig_f, p, p, p, p, nullptr, 0, 0.0, 1.0);   // T^T = Q Sigma_f^T (standard.py:175)
         for (int e = threadIdx.x; e < p * p; e += DT) w.A4[e] = Sig_s[e] - w.A2[e];        // Sigma_next - Sigma-
         for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = mu_s[i] - w.mup[i];
         __syncthreads();
-        wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv);                // A3 <- G^T = solve(Sigma-, T^T)   (standard.py:176)
+        wg_lu_solve(lds, w.A2, p, w.A3, p, p, p, w.piv);                // A3 <- G^T = solve(Sigma-, T^T)   (standard.py:176)
         for (int i = threadIdx.x; i < p; i += DT) {
             double s = 0.0;
             for (int j = 0; j < p; ++j) s = fma(w.A3[(size_t)j * p + i], w.dm[j], s);
             w.mup[i] = mu_f[i] + s;                                // standard.py:213-214 (written after the barrier)
         }
-        wg_gemm<true, false>(w.A1, p, w.A3, p, w.A4, p, p, p, p, nullptr, 0, 0.0, 1.0);    // G D
+        wg_gemm<true, false>(lds, w.A1, p, w.A3, p, w.A4, p, p, p, p, nullptr, 0, 0.0, 1.0);    // G D
         for (int i = threadIdx.x; i < p; i += DT) mu_f[i] = w.mup[i];
-        wg_gemm<false, false>(Sig_f, p, w.A1, p, w.A3, p, p, p, p, Sig_f, p, 1.0, 1.0);    // Sigma_f + (G D) G^T (standard.py:215-216)
+        wg_gemm<false, false>(lds, Sig_f, p, w.A1, p, w.A3, p, p, p, p, Sig_f, p, 1.0, 1.0);    // Sigma_f + (G D) G^T (standard.py:215-216)
     }
 }
 
@@ -430,6 +514,7 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
     RK_REQUIRE(c->n_bmeas >= 1 && c->n_bstate % c->n_bmeas == 0 && c->n_bstate / c->n_bmeas >= 2, RK_ERR_INVALID,
                "dense linear ODE: n_bstate (%d) must be n_vars * n_deriv with n_vars = n_bmeas (%d), n_deriv >= 2",
                c->n_bstate, c->n_bmeas);
+    RK_REQUIRE(c->n_bstate <= 768, RK_ERR_UNSUPPORTED, "dense path: n_bstate = %d exceeds 768 (LDS staging of the GEMMs)", c->n_bstate);
     RK_REQUIRE(mode != RK_MODE_SIM, RK_ERR_UNSUPPORTED, "dense path: solve_sim is not available yet");
     RK_REQUIRE(c->interrogate != RK_INTERROGATE_CHKREBTII, RK_ERR_UNSUPPORTED,
                "dense path: interrogate_chkrebtii is not available yet");

@@ -83,6 +83,9 @@ def c5(args):
     p, m = 160, 32
     F = (12 + 2 / 3) * p ** 3 + 4 * m * p * p + 4 * m * m * p + (2 / 3) * m ** 3
     ms = sum(prof.values())
+    if os.environ.get("RK_DENSE_STAMPS"):
+        ws = plan._ws.to_host().reshape(B, -1)
+        print("bwd phase cycles (wg 0): predict, T, diff, LU+solve, mean+GD, GDG^T =", ws[0, -8:-2] / (N - 1), file=sys.stderr)
     return {"config": f"C5 dense p=160 m=32 N={N} B={B} solve_mv+kramer", "ms": ms, "kernels_ms": prof,
             "traj_steps_per_s": B * N / ms * 1e3, "tflops": F * B * N / (ms * 1e-3) / 1e12,
             "frac_fp64_peak_78.6TF": F * B * N / (ms * 1e-3) / 78.6e12, "wall_s": wall}
