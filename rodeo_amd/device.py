@@ -103,6 +103,14 @@ class DeviceArray:
             _lib.check(self.dev.lib.rk_d2h(self.dev.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
         return out
 
+    def upload(self, host):
+        """Overwrite the buffer with a host array of the same shape and dtype (asynchronous-safe: rk_h2d synchronises)."""
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.shape != tuple(self.shape):
+            raise ValueError(f"upload: shape {host.shape} != {tuple(self.shape)}")
+        if self.nbytes:
+            _lib.check(self.dev.lib.rk_h2d(self.dev.h, self.ptr, host.ctypes.data_as(C.c_void_p), self.nbytes))
+
     def slice0_host(self, i):
         """Download only the i-th slice along the leading axis."""
         out = np.empty(self.shape[1:], self.dtype)

@@ -1,7 +1,10 @@
 """
 Callers of the hot path (SURVEY.md section 8f "next-1"): ``basic`` (src/rodeo/inference/basic.py) and the device-side
 Gaussian observation log-posterior reduction used by pseudo-marginal log-posteriors
-(docs/examples/parameter.md:188-210, 331-354).  fenrir / dalton / magi and the blackjax driver are out of scope.
+(docs/examples/parameter.md:188-210, 331-354), and ``pseudo_marginal``: the random-walk Rosenbluth-Metropolis-Hastings
+kernels of src/rodeo/inference/pseudo_marginal.py for many chains in lock-step (SURVEY.md section 8f "next-2").
+fenrir / dalton / magi are out of scope.
 """
 from .basic import basic
 from .logpost import gauss_obs_logpost, obs_index
+from . import pseudo_marginal

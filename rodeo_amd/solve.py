@@ -70,6 +70,7 @@ class SolvePlan:
             raise TypeError("ode_fun must be a rodeo_amd.ode.DeviceODE: the time loop runs on the GPU and needs device "
                             "code for the right-hand side (see rodeo_amd/ode.py); there is no CPU fallback")
         self.dev = device if device is not None else default_device()
+        self._ode_fun = ode_fun
         itg_id, bound = _interrogate_id(interrogate)
         if itg_id == _lib.INTERROGATE_CHKREBTII:
             kt = bound.get("kalman_type", params.pop("kalman_type", None) if "kalman_type" in params else None)
@@ -126,6 +127,24 @@ class SolvePlan:
         self._ws = None                    # device scratch for the dense path
         self.mean_state = self.var_state = self.mean_pred = self.var_pred = self.x_state = None
         self._out = _lib.SolveOut()
+
+    def update(self, ode_init=None, prior_pars=None, **params):
+        """
+        Replace inputs of the same shapes in place (device buffers and outputs are reused) -- what a sampler does between
+        two log-density evaluations: new initial values, prior scales and ODE parameters for every trajectory.
+        """
+        if ode_init is not None:
+            x0 = np.asarray(ode_init, dtype=np.float64)
+            self._x0.upload(_bm(x0, x0.ndim == 3))
+        if prior_pars is not None:
+            Q, R = (np.asarray(a, dtype=np.float64) for a in prior_pars)
+            self._Q.upload(_bm(Q, Q.ndim == 4))
+            self._R.upload(_bm(R, R.ndim == 4))
+        if params:
+            theta, Bt = self._ode_fun.pack_params(params)
+            if self._theta is None:
+                raise TypeError("this ODE has no parameters")
+            self._theta.upload(_bm(theta, Bt is not None))
 
     def _prepare_out(self, mode):
         """Ask the library which layout this call uses and (once) allocate the outputs for it."""

@@ -95,3 +95,43 @@ def test_chkrebtii_pseudo_marginal_logposterior(ra):
     np.testing.assert_allclose(lp, ref2, rtol=1e-12, atol=1e-9)
     with pytest.raises(ValueError):
         gauss_obs_logpost(plan, s["Y"], ind + 1000, sd)
+
+
+def test_lockstep_pseudo_marginal_chain_on_device(ra):
+    """
+    docs/examples/parameter.md:372-390 for C chains in lock-step: the device log-posterior (SolvePlan.update + solve_sim
+    with interrogate_chkrebtii + reduction) inside rodeo_amd.inference.pseudo_marginal's random-walk kernel, against
+    the same chain driven by the oracle's log-posterior with the same keys (draws share the Philox stream, so the two
+    chains make the same decisions and stay equal to rounding).
+    """
+    from rodeo_amd.inference import pseudo_marginal as pm
+    s = _setup(ra, n_steps=60, t_max=3.0, n_obs=4)
+    C, N, t_max, sd = 12, s["N"], s["t_max"], np.sqrt(0.005)
+    logpost = pm.FitzLogPosterior(s["Y"], s["obs_times"], 0.0, t_max, N, sd, n_chains=C)
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    o = functools.partial(oi.interrogate_chkrebtii, kalman_type="standard")
+
+    def oracle_logpost(upars, key):
+        theta, x0v, sigma = np.exp(upars[:, :3]), upars[:, 3:5], upars[:, 5:7]
+        X0 = init(x0v, 0.0, theta=theta)
+        pq = [priors.ibm_init(t_max / N, 3, sigma[c]) for c in range(C)]       # per-chain prior scales
+        prior = (np.stack([q for q, _ in pq]), np.stack([r for _, r in pq]))
+        xo = scan.solve_sim(key, odes.fitzhugh_nagumo, W, X0, 0.0, t_max, N, o, prior, theta=theta)
+        return np.array([np.sum(norm.logpdf(s["Y"], loc=xo[b][s["ind"], :, 0], scale=sd)) +
+                         np.sum(norm.logpdf(upars[b, :5], 0.0, 10.0)) for b in range(C)]), None
+
+    u0 = np.concatenate([np.log(s["theta"]), [-1.0, 1.0], [0.1, 0.1]])
+    start = u0 + np.array([0.01, 0.1, 0.01, 0.01, 0.01, 0.005, 0.005]) * np.random.default_rng(5).standard_normal((C, 7))
+    rw_sd = np.array([0.01, 0.1, 0.01, 0.01, 0.01, 0.01, 0.01])                 # parameter.md:372-373
+    dev_alg, ora_alg = pm.normal_random_walk(logpost, rw_sd), pm.normal_random_walk(oracle_logpost, rw_sd)
+    sd_state, so_state = dev_alg.init(start, 77), ora_alg.init(start, 77)
+    np.testing.assert_allclose(sd_state.logdensity, so_state.logdensity, rtol=1e-6, atol=1e-5)
+    n_acc = 0
+    for k in range(6):
+        sd_state, info_d = dev_alg.step(1000 + k, sd_state)
+        so_state, info_o = ora_alg.step(1000 + k, so_state)
+        np.testing.assert_array_equal(info_d.is_accepted, info_o.is_accepted)
+        np.testing.assert_array_equal(sd_state.position, so_state.position)
+        np.testing.assert_allclose(sd_state.logdensity, so_state.logdensity, rtol=1e-6, atol=1e-5)
+        n_acc += int(info_d.is_accepted.sum())
+    assert 0 < n_acc < 6 * C and np.all(np.isfinite(sd_state.logdensity))

@@ -1,0 +1,116 @@
+"""
+Host logic of ``rodeo_amd.inference.pseudo_marginal`` (src/rodeo/inference/pseudo_marginal.py for many chains in
+lock-step): key stream pinned by the Random123-pinned oracle Philox, one step against the per-chain restatement with the
+same draws, and exact-target checks (plain and pseudo-marginal).  blackjax itself is not installed: its bit-stream is
+"parity unpinned".  No GPU needed: the log-densities here are NumPy functions.
+"""
+import numpy as np
+import pytest
+from oracle import counter_rng, pseudo_marginal as opm
+
+pm = pytest.importorskip("rodeo_amd.inference.pseudo_marginal")
+
+
+def test_key_stream_is_the_pinned_philox():
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 2 ** 32, size=(50, 4), dtype=np.uint64)
+    k0, k1 = 0x12345678, 0x9ABCDEF0
+    got = pm._philox(c, k0, k1)
+    for i in range(50):
+        ref = counter_rng.philox4x32_10(*(np.uint32(v) for v in c[i]), np.uint32(k0), np.uint32(k1))
+        assert [int(v) for v in got[i]] == [int(v) for v in ref]
+    # sub-keys: deterministic, distinct, and different keys give different streams
+    a, b = pm.split(7, 3), pm.split(7, 3)
+    assert a == b and len(set(a)) == 3 and set(a).isdisjoint(pm.split(8, 3))
+    u = pm.uniform(5, (1000,)); z = pm.standard_normal(5, (2001,))
+    assert 0 < u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.03
+    assert abs(z.mean()) < 0.08 and abs(z.std() - 1) < 0.06 and z.shape == (2001,)
+
+
+def _target(x):                       # N(0, I) in 3-D, per chain
+    return -0.5 * np.sum(np.asarray(x) ** 2, axis=-1)
+
+
+def test_one_step_against_restatement():
+    C, dim, sigma = 64, 3, np.array([0.5, 1.0, 2.0])
+    rng = np.random.default_rng(1)
+    pos = rng.standard_normal((C, dim))
+    noise = lambda x, key: 0.3 * pm.standard_normal(key, (len(x),))             # a noisy (pseudo-marginal) log-density
+    logd = lambda x, key: (_target(x) + noise(x, key), {"n": noise(x, key)})
+    alg = pm.normal_random_walk(logd, sigma)
+    state = alg.init(pos, 11)
+    assert state.position.shape == (C, dim) and state.logdensity.shape == (C,)
+    new, info = alg.step(12, state)
+    kp, ka, kl = pm.split(12, 3)
+    inc = pm.standard_normal(kp, (C, dim)) * sigma
+    u = pm.uniform(ka, (C,))
+    ld_new_all, aux_new_all = logd(pos + inc, kl)
+    ref = opm.rmh_step(state.position, state.logdensity, [state.auxdata["n"][c] for c in range(C)], inc, u,
+                       lambda c, x: (ld_new_all[c], aux_new_all["n"][c]))
+    np.testing.assert_array_equal(new.position, ref[0])
+    np.testing.assert_array_equal(new.logdensity, ref[1])
+    np.testing.assert_array_equal(new.auxdata["n"], np.array(ref[2]))
+    np.testing.assert_array_equal(info.is_accepted, ref[3])
+    np.testing.assert_allclose(info.acceptance_rate, ref[4], rtol=1e-15)
+    assert 0 < info.is_accepted.sum() < C
+    np.testing.assert_array_equal(info.proposal.position, pos + inc)
+
+
+def test_nan_and_inf_logdensities_are_rejected_or_accepted_like_blackjax():
+    pos = np.zeros((4, 1))
+    vals = np.array([np.nan, -np.inf, np.inf, 0.0])
+    alg = pm.normal_random_walk(lambda x, key: (vals.copy(), None), np.array([1.0]))
+    state = pm.RWAState(pos, np.zeros(4), None)
+    new, info = alg.step(3, state)
+    assert list(info.is_accepted[:3]) == [False, False, True]
+    assert info.acceptance_rate[0] == 0.0 and info.acceptance_rate[1] == 0.0 and info.acceptance_rate[2] == 1.0
+
+
+@pytest.mark.parametrize("noisy", [False, True])
+def test_exact_target_and_pseudo_marginal_invariance(noisy):
+    """Many chains in lock-step sample N(0, 1); with an unbiased noisy density estimate (log-normal weight of mean 1)
+    the pseudo-marginal chain keeps the same target (the old noisy value is retained on rejection)."""
+    C, steps, s2 = 4000, 120, 0.5
+    def logd(x, key):
+        ld = -0.5 * x[:, 0] ** 2
+        if noisy:
+            ld = ld + np.sqrt(s2) * pm.standard_normal(key, (len(x),)) - 0.5 * s2      # log W, E[W] = 1
+        return ld, None
+    alg = pm.normal_random_walk(logd, np.array([1.5]))
+    state = alg.init(np.zeros((C, 1)), 100)
+    acc = 0
+    for k in range(steps):
+        state, info = alg.step(1000 + k, state)
+        acc += info.is_accepted.mean()
+    x = state.position[:, 0]
+    assert abs(x.mean()) < 0.08 and abs(x.var() - 1.0) < 0.12
+    assert 0.2 < acc / steps < 0.8
+
+
+def test_rmh_and_irmh_apis():
+    C = 500
+    logd = lambda x, key: (-0.5 * np.sum((x - 1.0) ** 2, axis=-1), None)
+    # independent proposals from N(0, 2^2): needs the proposal log-density (asymmetric ratio)
+    prop = lambda key: 2.0 * pm.standard_normal(key, (C, 1))
+    # the reference's convention (pseudo_marginal.py:446-447 with blackjax's ratio): the function is called as
+    # f(new_state, prev_state) inside the energy of the move prev -> new and must return log q(prev | new), here log q(prev)
+    qlog = lambda new_state, prev_state: -0.5 * np.sum(prev_state.position ** 2, axis=-1) / 4.0
+    alg = pm.irmh(logd, prop, qlog)
+    state = alg.init(np.zeros((C, 1)), 1)
+    for k in range(60):
+        prev = state
+        state, info = alg.step(50 + k, state)
+    assert abs(state.position.mean() - 1.0) < 0.15 and abs(state.position.var() - 1.0) < 0.25
+    # the last step against the per-chain restatement (asymmetric ratio)
+    kp, ka, kl = pm.split(50 + 59, 3)
+    xn = prop(kp)
+    ref = opm.rmh_step(prev.position, prev.logdensity, None, xn - prev.position, pm.uniform(ka, (C,)),
+                       lambda c, x: (float(logd(x[None], None)[0][0]), None),
+                       proposal_logdensity=lambda xa, xb: -0.5 * float(np.sum(xb ** 2)) / 4.0)
+    np.testing.assert_array_equal(info.is_accepted, ref[3])
+    np.testing.assert_allclose(state.position, ref[0], rtol=0, atol=1e-15)
+    alg2 = pm.rmh(logd, lambda key, position: position + 0.7 * pm.standard_normal(key, position.shape))
+    s2 = alg2.init(np.zeros((C, 1)), 2)
+    for k in range(80):
+        s2, _ = alg2.step(500 + k, s2)
+    assert abs(s2.position.mean() - 1.0) < 0.2
