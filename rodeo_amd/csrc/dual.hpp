@@ -90,6 +90,7 @@ struct AutoJac {
     static constexpr int NTHETA = U::NTHETA;
     static constexpr int NDEP = U::NDEP;
     static constexpr bool HAS_TILE_FORM = false;
+    static constexpr bool HAS_TILE3_FORM = false;
     template <int P>
     __device__ __forceinline__ static void f(const double (&X)[D][P], double t, const double (&th)[NTHETA],
                                              double (&out)[D]) {

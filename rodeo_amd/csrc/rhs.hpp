@@ -53,6 +53,7 @@ struct FitzHughNagumo {
     // instead of both blocks plus selects (11 fewer VALU instructions per step).  Same function as f / fjac; the
     // association differs from the reference expression at rounding level (c V - (c/3) V^3 + c R).
     static constexpr bool HAS_TILE_FORM = true;
+    static constexpr bool HAS_TILE3_FORM = false;
     static constexpr int NTILEK = 6;
     __device__ __forceinline__ static void tile_consts(int blk, const double (&th)[NTHETA], double (&k)[NTILEK]) {
         const double a = th[0], b = th[1], c = th[2];
@@ -94,6 +95,21 @@ struct Lorenz63 {
         J[2][0] = -th[2];
     }
     static constexpr bool HAS_TILE_FORM = false;
+    // Optional three-block "tile form" used by the p = 4 MFMA-tile forward kernel: every lane evaluates only ITS block's
+    // f_b from its own first state and those of the next / previous / second-previous block of the trajectory
+    // (n1, p1, p2; cyclic in the DPP row, unused neighbours have zero coefficients),
+    //     f_b = k0 own + k1 n1 + k2 p1 + k3 (p1 n1) + k4 (p2 p1),      d f_b / d X[b][0] = k0  (a constant),
+    // instead of all three blocks plus selects.  Same function as f / fjac.
+    static constexpr bool HAS_TILE3_FORM = true;
+    __device__ __forceinline__ static void tile3_consts(int blk, const double (&th)[NTHETA], double (&k)[5]) {
+        const double rho = th[0], sigma = th[1], beta = th[2];
+        // (plain selects: an if / else-if chain over a zero-initialised array came out of hipcc with block 2's k0 = -1)
+        k[0] = blk == 0 ? -sigma : (blk == 1 ? -1.0 : -beta);      // x' = -sigma x + sigma y
+        k[1] = blk == 0 ? sigma : 0.0;                              // y' = -y + rho x - x z
+        k[2] = blk == 1 ? rho : 0.0;                                // z' = -beta z + x y
+        k[3] = blk == 1 ? -1.0 : 0.0;
+        k[4] = blk == 2 ? 1.0 : 0.0;
+    }
 };
 
 // Second-order ODE of Chkrebtii et al, docs/examples/higher_order.md:47-59:  x'' = sin(2t) - x.
@@ -115,6 +131,7 @@ struct HigherOrder {
         J[0][0] = -1.0;
     }
     static constexpr bool HAS_TILE_FORM = false;
+    static constexpr bool HAS_TILE3_FORM = false;
 };
 
 }  // namespace rk

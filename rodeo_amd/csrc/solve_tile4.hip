@@ -19,6 +19,7 @@
 namespace rk {
 
 constexpr int T4_DOUBLES = 20;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 template <int D>
 struct Tpw {                                     // tiles per wave
@@ -90,6 +91,50 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
     const size_t tstride_all = (size_t)n_tiles * T4_DOUBLES;
     double* const dump = tiles + (size_t)(a.N + 1) * tstride_all + (size_t)blockIdx.x * 128;
     const bool st_m = tc.valid && c == 0;
+    if constexpr (RHS::HAS_TILE3_FORM && D == 3) {
+        // Lorenz63-type right-hand sides (config C3) in hand-trimmed form, after fwd_tile3_kernel: every instruction of
+        // the wave lies on the step's dependent chain, so -- per-lane coefficients instead of three blocks + selects
+        // (the measurement row W~ = W - J is constant, the offset a = J mu- - f is a bilinear form of this block's and
+        // its neighbours' evaluation points, fetched with three plain DPP row rotations), cubic reciprocal step,
+        // buffer stores with a scalar row base (slot-less lanes dropped by the range check).
+        double kk[5];
+        RHS::tile3_consts(blk, th, kk);
+        const bool jac = ITG == RK_INTERROGATE_KRAMER;
+        const double c0 = jac ? 0.0 : -kk[0], c1 = -kk[1], c2 = -kk[2], c3 = -kk[3], c4 = -kk[4];   // a = -f + J0 own
+        const double Xw = fma(jac ? -kk[0] : 0.0, E0, Wr);          // W~ = W - J, row form (solve.py:79): constant
+        const char* row = (const char*)(tiles + (size_t)blockIdx.x * Tpw<D>::value * T4_DOUBLES);
+        const int voS = tc.valid ? (int)((tc.g * T4_DOUBLES + r * 4 + c) * sizeof(double)) : (int)0x80000000;
+        const int voM = st_m ? (int)((tc.g * T4_DOUBLES + 16 + r) * sizeof(double)) : (int)0x80000000;
+        auto store_row = [&](double vS, double vM) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, Tpw<D>::value * T4_DOUBLES * 8, 0x00020000);
+            u32x2 bS, bM;
+            __builtin_memcpy(&bS, &vS, 8);
+            __builtin_memcpy(&bM, &vM, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(bS, rsrc, voS, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(bM, rsrc, voM, 0, 0);
+        };
+        store_row(S, m);
+        for (int n = 0; n < a.N; ++n) {
+            const double U = MF(S, Qt, 0.0);
+            const double v_own = MF(Y0, m, 0.0);                      // (Q mu)_0 in all 16 lanes of the tile
+            const double mp = MF(Qt, m, 0.0);                         // Q mu, row form
+            const double SpT = MF(Qt, U, RtT);                        // exact transpose of S-: Q Sigma^T Q^T + R^T
+            const double Sp = MF(U, Qt, Rt);                          // Q Sigma Q^T + R
+            const double n1 = from_next_tile(v_own), p1 = from_prev_tile(v_own), p2 = dpp64<0x128>(v_own);
+            const double a_meas = fma(c4, p2 * p1, fma(c3, p1 * n1, fma(c2, p1, fma(c1, n1, c0 * v_own))));
+            const double Z = MF(SpT, Xw, 0.0);                        // Sigma- W~^T (standard.py:97), row form
+            const double WS = MF(Xw, Sp, 0.0);
+            const double yhat = MF(Xw, mp, a_meas);
+            double Sc = MF(Z, Xw, 0.0);
+            if constexpr (ITG == RK_INTERROGATE_RODEO) Sc = Sc + Sc;  // var_meas = W Sigma- W^T (interrogate.py:110-113)
+            const double K = -Z * fast_rcp_cubic(Sc);
+            S = fma(K, WS, Sp);
+            m = fma(K, yhat, mp);
+            row += tstride_all * sizeof(double);
+            store_row(S, m);
+        }
+        return;
+    }
     double* oS = tc.valid ? tiles + (size_t)tc.tau * T4_DOUBLES + r * 4 + c : dump + threadIdx.x;
     double* oM = st_m ? tiles + (size_t)tc.tau * T4_DOUBLES + 16 + r : dump + 64 + threadIdx.x;
     const size_t sS = tc.valid ? tstride_all : 0, sM = st_m ? tstride_all : 0;

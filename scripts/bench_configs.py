@@ -29,8 +29,12 @@ def c3(args):
     plan = ra.SolvePlan(ra.ode.lorenz63, W, x0, 0.0, 20.0, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
     ms = timeit(lambda: plan.mv(None), plan.dev, 2)
     a = 3 * 3 * p * (p + 1) * 8
+    plan.dev.profile_enable(True)
+    plan.mv(None); plan.dev.sync()
+    kern = dict(plan.dev.profile_last())
+    plan.dev.profile_enable(False)
     return {"config": "C3 Lorenz63 d=3 p=4 N=20000 B=512 solve_mv+kramer", "ms": ms, "traj_steps_per_s": B * N / ms * 1e3,
-            "hbm_frac_solve": a * B * N / (ms * 1e-3) / 8e12, "layout": plan.layout}
+            "hbm_frac_solve": a * B * N / (ms * 1e-3) / 8e12, "layout": plan.layout, "kernels_ms": kern}
 
 
 def c4(args):
