@@ -189,99 +189,132 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------
+// Same structure as bwd_mv_tile3_kernel (read its comments first): 4-wave workgroups, wave 0 consumes the 16-step
+// chunks, waves 1..3 produce them in three pipeline stages; LDS-DMA prefetch of the filtered tiles, hand-off through
+// LDS with the conflict-free swizzles of mfma_tile.hpp, consumer with software-pipelined LDS reads and buffer stores.
+// A wave carries TPW = 3 (n_block = 3: the three blocks of one trajectory) or 4 tiles; items are packed TPW to a time
+// step, so Lorenz63 (config C3) needs 48 + 24 KiB of LDS per workgroup and two workgroups share a CU.
 constexpr int CH4 = 16;                          // time steps per hand-off
 constexpr int ITEM4 = 512;                       // bytes per (step, tile): S- | G^T | S_f tiles, then m- (4), m_f (4)
-constexpr int BUF4 = CH4 * 4 * ITEM4;            // 32 KiB
 
+template <int TPW>
 __device__ __forceinline__ int lds4_tile(int s, int g, int which, int idx) {
-    const int item = s * 4 + g;
-    return item * ITEM4 + which * 128 + (tile_slot(s, g, idx) << 3);
+    return (s * TPW + g) * ITEM4 + which * 128 + (tile_slot(s, g, idx) << 3);
 }
+template <int TPW>
 __device__ __forceinline__ int lds4_vec(int s, int g, int which, int rr) {
-    const int item = s * 4 + g;
-    return item * ITEM4 + 384 + (vec_slot(s, g, which, rr) << 3);
+    return (s * TPW + g) * ITEM4 + 384 + (vec_slot(s, g, which, rr) << 3);
 }
 
 template <int D>
-__global__ void __launch_bounds__(512) bwd_mv_tile4_kernel(SolveArgs a, double* __restrict__ tiles) {
+__global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* __restrict__ tiles) {
     constexpr int P = 4, TPW = Tpw<D>::value;
-    __shared__ __attribute__((aligned(16))) char lds_all[2 * 2 * BUF4];
-    const int wave_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave_id == 4 || wave_id == 5) return;                      // placeholders: keep the consumers' SIMDs free
+    constexpr int BUF = CH4 * TPW * ITEM4;                         // 24 / 32 KiB
+    constexpr int ROW_BYTES = TPW * T4_DOUBLES * 8;                // this tile-wave's bytes per time row: 480 / 640
+    constexpr int N_DMA = (CH4 * ROW_BYTES / 16 + 63) / 64;        // 1-KiB LDS-DMA pieces per chunk: 8 / 10
+    constexpr int ZONE = N_DMA * 1024;
+    __shared__ __attribute__((aligned(16))) char lds_all[2 * BUF];
+    __shared__ __attribute__((aligned(16))) char zones[3 * ZONE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;    // 0 = consumer; producers q = wave - 1 own ch = q (mod 3)
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * T4_DOUBLES;
-    const int n_chunks = (a.N - 1 + CH4 - 1) / CH4;
+    const size_t row_bytes = tstride * sizeof(double);
+    const int n_chunks = (a.N - 1 + CH4 - 1) / CH4;                // steps n = N-1 .. 1
+    const int tw = blockIdx.x;                                     // tile-wave: tiles TPW tw .. TPW tw + TPW - 1
+    const char* const wave_rows = (const char*)(tiles + (size_t)tw * TPW * T4_DOUBLES);
 
-    const int grp = wave_id & 1;
-    const int role = wave_id < 2 ? 0 : (wave_id < 4 ? 1 : 2);      // 0 consumer, 1 / 2 producers of parity 0 / 1
-    const int tw = blockIdx.x * 2 + grp;                           // tile-wave: tiles TPW tw .. TPW tw + TPW - 1
-    char* const lds_raw = lds_all + grp * 2 * BUF4;
-    double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)tw * 128;
-
-    if (role >= 1) {
+    if (wave >= 1) {
         // ---------------- producers: one lane per (step-in-chunk, tile) ----------------
-        const int p = role - 1;
+        const int p = wave - 1;
         const int s = lane >> 2, g = lane & 3;
-        int tau = tw * TPW + (g < TPW ? g : 0);
+        const bool active = g < TPW;
+        int tau = tw * TPW + (active ? g : 0);
         if (tau >= n_tiles) tau = n_tiles - 1;
         const int b = tau / D, blk = tau - b * D;
         double Q[P][P], R[P][P];
         load_block_consts<P>(a, blk, b, Q, R);
-        const double* tin = tiles + (size_t)tau * T4_DOUBLES;
         int woff[16], voff[4], voff1[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) woff[i] = lds4_tile(s, g, 0, i);
+        for (int i = 0; i < 16; ++i) woff[i] = lds4_tile<TPW>(s, g, 0, i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { voff[i] = lds4_vec(s, g, 0, i); voff1[i] = lds4_vec(s, g, 1, i); }
-        double bufE[T4_DOUBLES], bufO[T4_DOUBLES];
-        auto fetch = [&](int ch, double (&dst)[T4_DOUBLES]) {
-            int n = a.N - 1 - ch * CH4 - s;
-            n = n < 1 ? 1 : n;
-            const double* in = tin + (size_t)n * tstride;
+        for (int i = 0; i < 4; ++i) { voff[i] = lds4_vec<TPW>(s, g, 0, i); voff1[i] = lds4_vec<TPW>(s, g, 1, i); }
+        // landing zone = image of the chunk's 16 time rows x ROW_BYTES; piece j = 64 i + lane (clamped in the last one)
+        char* const zone = zones + p * ZONE;
+        const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
+        int frow[N_DMA], fcol[N_DMA];
 #pragma unroll
-            for (int i = 0; i < T4_DOUBLES; ++i) dst[i] = in[i];
-        };
-        if (p < n_chunks) fetch(p, bufE);
-        if (p + 2 < n_chunks) fetch(p + 2, bufO);
-        double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P];
-        auto phaseA = [&](int chA, double (&buf)[T4_DOUBLES]) {
+        for (int i = 0; i < N_DMA; ++i) {
+            int j = 64 * i + lane;
+            j = j < CH4 * ROW_BYTES / 16 ? j : CH4 * ROW_BYTES / 16 - 1;
+            frow[i] = j / (ROW_BYTES / 16); fcol[i] = (j % (ROW_BYTES / 16)) * 16;
+        }
+        auto fetch = [&](int ch) {
+            const int n_hi = a.N - 1 - ch * CH4;
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-#pragma unroll
-                for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
-                mf[i] = buf[16 + i];
+            for (int i = 0; i < N_DMA; ++i) {
+                const int n = n_hi - frow[i];
+                lds_dma16(wave_rows + (size_t)(n < 1 ? 1 : n) * row_bytes + fcol[i], zone_lds + 1024 * i);
             }
-            if (chA + 4 < n_chunks) fetch(chA + 4, buf);
-            __builtin_amdgcn_sched_barrier(0);
-            predict_block<P>(Q, R, mf, Sf, mp, Sp);              // pred[n+1] from filt[n]   (standard.py:57-59)
-            mm_nt<P, P, P>(Sf, Q, T);                            // T = Sigma_f Q^T          (standard.py:175)
         };
-        for (int t = -2; t < n_chunks; ++t) {
-            const int chA = t + 2, chB = t + 1;
-            if ((chA & 1) == p) {
-                if (chA < n_chunks) {
-                    if ((chA >> 1) & 1) phaseA(chA, bufO); else phaseA(chA, bufE);
-                }
-            } else if (chB >= 0 && chB < n_chunks) {
-                double A[P][P], X[P][P];
+        lds_dma_wait_all();                                        // retire the loads of Q, R before the first DMA
+        if (p < n_chunks) fetch(p);
+        double mf[P], Sf[P][P], mp[P], Sp[P][P], A[P][P], X[P][P], rpiv[P];
+        for (int t = -3; t < n_chunks; ++t) {
+            const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
+            if (ch1 % 3 == p) {
+                // ---- stage 1 of chunk ch1: fetched tiles, next fetch, predict, T^T ----
+                if (ch1 < n_chunks) {
+                    lds_dma_wait_all();
+                    double buf[T4_DOUBLES];
+                    const char* mine = zone + s * ROW_BYTES + (active ? g : 0) * (T4_DOUBLES * 8);
 #pragma unroll
-                for (int i = 0; i < P; ++i)
-#pragma unroll
-                    for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
-                lu_solve<P, P>(A, X);                            // X = G^T                  (standard.py:176)
-                const int n = a.N - 1 - chB * CH4 - s;
-                if (n >= 1 && g < TPW) {
-                    char* o = lds_raw + (chB & 1) * BUF4;
+                    for (int k = 0; k < T4_DOUBLES / 2; ++k) {
+                        const double2 v = *(const double2*)(mine + 16 * k);
+                        buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
+                    }
+                    lds_reads_done();
+                    if (ch1 + 3 < n_chunks) fetch(ch1 + 3);
 #pragma unroll
                     for (int i = 0; i < P; ++i) {
 #pragma unroll
-                        for (int j = 0; j < P; ++j) {
-                            *(double*)(o + woff[i * 4 + j]) = Sp[i][j];
-                            *(double*)(o + woff[i * 4 + j] + 128) = X[i][j];
-                            *(double*)(o + woff[i * 4 + j] + 256) = Sf[i][j];
+                        for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
+                        mf[i] = buf[16 + i];
+                    }
+                    predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
+                    double T[P][P];
+                    mm_nt<P, P, P>(Sf, Q, T);                        // T = Sigma_f Q^T          (standard.py:175)
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) X[i][j] = T[j][i];
+                }
+            } else if (ch2 >= 0 && ch2 % 3 == p) {
+                // ---- stage 2 of chunk ch2: LU of Sigma- with the forward sweep on T^T ----
+                if (ch2 < n_chunks) {
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) A[i][j] = Sp[i][j];
+                    lu_factor_fwd<P, P>(A, X, rpiv);
+                }
+            } else if (ch3 >= 0) {
+                // ---- stage 3 of chunk ch3: back substitution, X = G^T (standard.py:176), hand-off ----
+                if (ch3 < n_chunks) {
+                    lu_back<P, P>(A, X, rpiv);
+                    const int n = a.N - 1 - ch3 * CH4 - s;
+                    if (n >= 1 && active) {
+                        char* o = lds_all + (ch3 & 1) * BUF;
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+#pragma unroll
+                            for (int j = 0; j < P; ++j) {
+                                *(double*)(o + woff[i * 4 + j]) = Sp[i][j];
+                                *(double*)(o + woff[i * 4 + j] + 128) = X[i][j];
+                                *(double*)(o + woff[i * 4 + j] + 256) = Sf[i][j];
+                            }
+                            *(double*)(o + voff[i]) = mp[i];
+                            *(double*)(o + voff1[i]) = mf[i];
                         }
-                        *(double*)(o + voff[i]) = mp[i];
-                        *(double*)(o + voff1[i]) = mf[i];
                     }
                 }
             }
@@ -290,44 +323,76 @@ __global__ void __launch_bounds__(512) bwd_mv_tile4_kernel(SolveArgs a, double* 
     } else {
         // ---------------- consumer ----------------
         const T4Coord tc = t4_coord<D>(tw, lane, n_tiles);
+        __builtin_amdgcn_s_setprio(3);
         const int r = tc.r, g = tc.g, c = tc.c, idx = r * 4 + c;
+        const int gl = g < TPW ? g : 0;                             // (idle tile slot: reads slot 0's items, stores nothing)
         const bool st_m = tc.valid && c == 0;
-        double* bS = tc.valid ? tiles + (size_t)tc.tau * T4_DOUBLES + idx : dump + lane;
-        double* bM = st_m ? tiles + (size_t)tc.tau * T4_DOUBLES + 16 + r : dump + 64 + lane;
-        const size_t sS = tc.valid ? tstride : 0, sM = st_m ? tstride : 0;
         // carry = filt[N]  (solve.py:279-282); the mean in row form
         double Ss = tc.valid ? tiles[(size_t)a.N * tstride + (size_t)tc.tau * T4_DOUBLES + idx] : 0.0;
         double ms = tc.valid ? tiles[(size_t)a.N * tstride + (size_t)tc.tau * T4_DOUBLES + 16 + r] : 0.0;
+        const int voS = tc.valid ? (int)((g * T4_DOUBLES + idx) * sizeof(double)) : (int)0x80000000;
+        const int voM = st_m ? (int)((g * T4_DOUBLES + 16 + r) * sizeof(double)) : (int)0x80000000;
+        const bool buffer_ok = (CH4 - 1) * row_bytes + ROW_BYTES < 0x7fffffffull;
+        const int chunk_span = (int)((CH4 - 1) * row_bytes + ROW_BYTES);
         int roff[4], rvec[4], rvec1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            roff[k] = lds4_tile(k, g, 0, idx) - k * 4 * ITEM4;
-            rvec[k] = lds4_vec(k, g, 0, r) - k * 4 * ITEM4;
-            rvec1[k] = lds4_vec(k, g, 1, r) - k * 4 * ITEM4;
+            roff[k] = lds4_tile<TPW>(k, gl, 0, idx) - k * TPW * ITEM4;
+            rvec[k] = lds4_vec<TPW>(k, gl, 0, r) - k * TPW * ITEM4;
+            rvec1[k] = lds4_vec<TPW>(k, gl, 1, r) - k * TPW * ITEM4;
         }
+        __syncthreads();                                            // tick -3
         __syncthreads();                                            // tick -2
         __syncthreads();                                            // tick -1: chunk 0 is in LDS
         for (int t = 0; t < n_chunks; ++t) {
-            const char* in = lds_raw + (t & 1) * BUF4;
+            const char* in = lds_all + (t & 1) * BUF;
             const int n_hi = a.N - 1 - t * CH4;
             const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CH4 ? CH4 : n_hi);
-            double* oS = bS + (size_t)n_hi * sS;
-            double* oM = bM + (size_t)n_hi * sM;
-            auto step = [&](const char* q, const char* qv, const char* qw) {
-                const double Sp = *(const double*)(q), Gt = *(const double*)(q + 128), Sf = *(const double*)(q + 256);
-                const double mp = *(const double*)(qv), mf = *(const double*)(qw);
-                const double V1 = MF(Ss - Sp, Gt, 0.0);             // (G D)^T
-                ms = MF(Gt, ms - mp, mf);                           // mu_f + G (mu_s - mu-)     (standard.py:213-214)
-                Ss = MF(V1, Gt, Sf);                                // Sigma_f + G D G^T         (standard.py:215-216)
-                oS[0] = Ss; oM[0] = ms;
-                oS -= sS; oM -= sM;
-            };
-            if (cnt == CH4) {
+            if (cnt == CH4 && buffer_ok) {
+                // branch-free chunk: LDS reads LOOKAHEAD steps ahead (five per step, lgkmcnt holds 15), three MFMAs,
+                // two subtractions and two buffer stores per step
+                constexpr int LOOKAHEAD = 2;
+                double Sp[CH4], Gt[CH4], Sf[CH4], mp[CH4], mf[CH4];
+                auto load = [&](int s) {
+                    const char* q = in + roff[s & 3] + s * TPW * ITEM4;
+                    Sp[s] = *(const double*)(q);
+                    Gt[s] = *(const double*)(q + 128);
+                    Sf[s] = *(const double*)(q + 256);
+                    mp[s] = *(const double*)(in + rvec[s & 3] + s * TPW * ITEM4);
+                    mf[s] = *(const double*)(in + rvec1[s & 3] + s * TPW * ITEM4);
+                };
 #pragma unroll
-                for (int s = 0; s < CH4; ++s) step(in + roff[s & 3] + s * 4 * ITEM4, in + rvec[s & 3] + s * 4 * ITEM4,
-                                                   in + rvec1[s & 3] + s * 4 * ITEM4);
+                for (int s = 0; s < LOOKAHEAD; ++s) load(s);
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(wave_rows + (size_t)(n_hi - (CH4 - 1)) * row_bytes), 0, chunk_span, 0x00020000);
+#pragma unroll
+                for (int s = 0; s < CH4; ++s) {
+                    if (s + LOOKAHEAD < CH4) load(s + LOOKAHEAD);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double V1 = MF(Ss - Sp[s], Gt[s], 0.0);       // (G D)^T
+                    ms = MF(Gt[s], ms - mp[s], mf[s]);                  // mu_f + G (mu_s - mu-)     (standard.py:213-214)
+                    Ss = MF(V1, Gt[s], Sf[s]);                          // Sigma_f + G D G^T         (standard.py:215-216)
+                    u32x2 bS, bM;
+                    __builtin_memcpy(&bS, &Ss, 8);
+                    __builtin_memcpy(&bM, &ms, 8);
+                    const int soff = (int)((CH4 - 1 - s) * row_bytes);
+                    __builtin_amdgcn_raw_buffer_store_b64(bS, rsrc, voS, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(bM, rsrc, voM, soff, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
-                for (int s = 0; s < cnt; ++s) step(in + lds4_tile(s, g, 0, idx), in + lds4_vec(s, g, 0, r), in + lds4_vec(s, g, 1, r));
+                for (int s = 0; s < cnt; ++s) {
+                    const char* q = in + lds4_tile<TPW>(s, gl, 0, idx);
+                    const double Sp = *(const double*)(q), Gt = *(const double*)(q + 128), Sf = *(const double*)(q + 256);
+                    const double mp = *(const double*)(in + lds4_vec<TPW>(s, gl, 0, r));
+                    const double mf = *(const double*)(in + lds4_vec<TPW>(s, gl, 1, r));
+                    const double V1 = MF(Ss - Sp, Gt, 0.0);
+                    ms = MF(Gt, ms - mp, mf);
+                    Ss = MF(V1, Gt, Sf);
+                    double* row = tiles + (size_t)(n_hi - s) * tstride + (size_t)tc.tau * T4_DOUBLES;
+                    if (tc.valid) row[idx] = Ss;
+                    if (st_m) row[16 + r] = ms;
+                }
             }
             __syncthreads();
         }
@@ -382,7 +447,7 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     else rc = launch_fwd_tile4<HigherOrder>(h, c, a, tiles);
     if (rc || mode == RK_MODE_FILTER || a.N < 2) return rc;
     const int tpw = a.D == 3 ? 3 : 4;
-    const dim3 grid(div_up(div_up(a.B * a.D, tpw), 2)), block(512);
+    const dim3 grid(div_up(a.B * a.D, tpw)), block(256);
     LaunchTimer t(h, "bwd_mv_tile4_kernel");
     if (a.D == 1) hipLaunchKernelGGL((bwd_mv_tile4_kernel<1>), grid, block, 0, h->stream, a, tiles);
     else if (a.D == 2) hipLaunchKernelGGL((bwd_mv_tile4_kernel<2>), grid, block, 0, h->stream, a, tiles);
