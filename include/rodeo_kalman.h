@@ -188,6 +188,16 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
                          int32_t n_obs, double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
                          double* logpost);
 
+/* Fenrir's backward pass (src/rodeo/inference/fenrir.py:86-259; the forward pass is rk_solve_filter with
+ * RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR, fenrir.py:304-313): log p(y_{0:M} | Z_{1:N}) per trajectory from the
+ * stored filtered and predicted moments in `out` (same cfg / in as the filter call).  Observations are scalar per
+ * block (n_bobs = 1): obs (n_obs, d), obs_weight (n_obs, d, p), obs_var (n_obs, d) row-major on device, shared by all
+ * trajectories; obs_ind (n_obs) = searchsorted(sim_times, obs_times), ascending.  logdens (B) is overwritten.
+ * The log-density follows src/rodeo/utils.py:60-78 (a forecast variance with |w| <= 1e-8 contributes nothing).      */
+int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
+                       const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
+                       int32_t n_obs, double* logdens);
+
 /* ---- per-step operator boundary -------------------------------------------------------------------------
  * Batched versions of the nine functions of src/rodeo/kalmantv/standard.py (kalman_type = RK_KALMAN_STANDARD)
  * and src/rodeo/kalmantv/square_root.py (RK_KALMAN_SQRT).  n = batch size (the reference's vmap axis);

@@ -150,6 +150,93 @@ __global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile,
     out[b] = acc;
 }
 
+// ---- Fenrir backward pass (src/rodeo/inference/fenrir.py:86-259), scalar observations per block --------------------
+// One lane per (block, trajectory): the backward Markov chain X_n = A_n X_{n+1} + b_n + C_n^{1/2} eps
+// (smooth_cond, standard.py:366-370) is run as a Kalman filter backwards in time over the stored forward moments
+// (batch-minor filt and pred), conditioning on the observations y_i = D_i X_{n(i)} + N(0, Omega_i) at their grid
+// indices; every observation contributes log N(y_i; D m, D S D^T + Omega) with utils.py:60-78's rule that a variance
+// with |w| <= 1e-8 contributes nothing (jnp.isclose(w, 0, rtol=1e-300)).  Block values are summed per trajectory.
+template <int P>
+__global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const double* __restrict__ obs,
+                                                        const double* __restrict__ obs_w, const double* __restrict__ obs_v,
+                                                        const int32_t* __restrict__ obs_ind, int n_obs,
+                                                        double* __restrict__ logdens) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.B * a.D) return;
+    const int blk = l / a.B, b = l - blk * a.B;
+    const size_t B = (size_t)a.B;
+    const double LOG_2PI = 1.83787706640934548356;
+    double Q[P][P], R[P][P];
+    load_block_consts<P>(a, blk, b, Q, R);
+    double bm[P], bS[P][P];
+    load_filt<P>(a, a.N, blk, b, bm, bS);                                   // terminal point (fenrir.py:186-188)
+    double acc = 0.0;
+    int i = n_obs - 1;
+    // forecast (standard.py:333-335) + log-density + update (standard.py:93-102) with observation i
+    auto observe = [&](double (&m)[P], double (&S)[P][P]) {
+        double D[P], SD[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) D[k] = obs_w[((size_t)i * a.D + blk) * P + k];
+        const double y = obs[(size_t)i * a.D + blk], Om = obs_v[(size_t)i * a.D + blk];
+        const double mean_fore = dot<P>(D, m);
+#pragma unroll
+        for (int r = 0; r < P; ++r) SD[r] = dot<P>(S[r], D);                // Sigma D^T
+        double DS[P];
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            double t = D[0] * S[0][c];
+#pragma unroll
+            for (int k = 1; k < P; ++k) t = fma(D[k], S[k][c], t);
+            DS[c] = t;                                                      // D Sigma
+        }
+        const double w = dot<P>(DS, D) + Om;                                // var_fore
+        const double z = y - mean_fore;
+        if (fabs(w) > 1e-8) acc += -0.5 * (z * z / w + log(w)) - 0.5 * LOG_2PI;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            const double K = SD[r] / w;                                     // solve_var with a 1 x 1 system
+            m[r] = fma(K, z, m[r]);
+#pragma unroll
+            for (int c = 0; c < P; ++c) S[r][c] = fma(-K, DS[c], S[r][c]);
+        }
+        --i;
+    };
+    if (i >= 0 && obs_ind[i] >= a.N) observe(bm, bS);                      // fenrir.py:189-209
+    for (int n = a.N - 1; n >= 0; --n) {
+        double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P], G[P][P];
+        load_filt<P>(a, n, blk, b, mf, Sf);
+        {   // stored predicted moments of time n + 1 (solve.py:93-96)
+            const double* mi = a.mean_pred + ((size_t)(n + 1) * a.D + blk) * P * B + b;
+            const double* vi = a.var_pred + ((size_t)(n + 1) * a.D + blk) * P * P * B + b;
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                mp[r] = mi[(size_t)r * B];
+#pragma unroll
+                for (int c = 0; c < P; ++c) Sp[r][c] = vi[((size_t)r * P + c) * B];
+            }
+        }
+        smooth_gain<P>(Q, Sf, Sp, T, G);                                    // A = G            (standard.py:175-176)
+        double bb[P], Cc[P][P], GT[P][P];
+        mm_nt<P, P, P>(G, T, GT);
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            bb[r] = mf[r] - dot<P>(G[r], mp);                               // b = mu_f - G mu-   (standard.py:368)
+#pragma unroll
+            for (int c = 0; c < P; ++c) Cc[r][c] = Sf[r][c] - GT[r][c];     // C = Sigma_f - G T^T (standard.py:369-370)
+        }
+        double nm[P], nS[P][P];
+        predict_block<P>(G, Cc, bm, bS, nm, nS);                            // A m + 0, A S A^T + C (standard.py:57-59)
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            bm[r] = nm[r] + bb[r];
+#pragma unroll
+            for (int c = 0; c < P; ++c) bS[r][c] = nS[r][c];
+        }
+        if (i >= 0 && obs_ind[i] == n) observe(bm, bS);                     // fenrir.py:155-170
+    }
+    atomicAdd(&logdens[b], acc);
+}
+
 // ---- dispatch ---------------------------------------------------------------------------------------------------
 static int make_args(const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, SolveArgs& a) {
     a.B = c->n_traj; a.N = c->n_steps; a.D = c->n_block;
@@ -444,6 +531,36 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
     hipLaunchKernelGGL(gauss_logpost_kernel, dim3(div_up(n_traj, 64)), dim3(64), 0, h->stream, n_traj, n_steps, n_block,
                        n_bstate, layout == RK_LAYOUT_TILE3 ? 12 : (layout == RK_LAYOUT_TILE4 ? 20 : 0),
                        layout == RK_LAYOUT_TILE3 ? 3 : 16, x_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out,
+                       const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
+                       int32_t n_obs, double* logdens) {
+    RK_REQUIRE(h && c && in && out && obs && obs_weight && obs_var && obs_ind && logdens, RK_ERR_INVALID,
+               "rk_fenrir_backward: null argument");
+    RK_REQUIRE(out->mean_state && out->var_state && out->mean_pred && out->var_pred, RK_ERR_INVALID,
+               "rk_fenrir_backward needs the batch-minor filtered AND predicted moments of rk_solve_filter "
+               "(RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_backward: kalman_type must be standard");
+    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6 && n_obs >= 0, RK_ERR_UNSUPPORTED,
+               "rk_fenrir_backward: n_bstate in 2..6, scalar observations per block");
+    SolveArgs a;
+    int rc = make_args(c, in, out, a);
+    if (rc) return rc;
+    RK_HIP(hipSetDevice(h->device));
+    RK_HIP(hipMemsetAsync(logdens, 0, sizeof(double) * (size_t)c->n_traj, h->stream));
+    const dim3 grid(div_up(a.B * a.D, 64)), block(64);
+    LaunchTimer t(h, "fenrir_bwd_kernel");
+    switch (c->n_bstate) {
+        case 2: hipLaunchKernelGGL(fenrir_bwd_kernel<2>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
+        case 3: hipLaunchKernelGGL(fenrir_bwd_kernel<3>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
+        case 4: hipLaunchKernelGGL(fenrir_bwd_kernel<4>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
+        case 5: hipLaunchKernelGGL(fenrir_bwd_kernel<5>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
+        default: hipLaunchKernelGGL(fenrir_bwd_kernel<6>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
+    }
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

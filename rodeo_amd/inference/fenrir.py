@@ -1,0 +1,46 @@
+"""
+``rodeo.inference.fenrir`` (src/rodeo/inference/fenrir.py:261-327): the Fenrir approximate log-likelihood
+log p(Y_{0:M} | Z_{1:N}) -- forward filter (``_solve_filter``, storing the predicted moments), then the backward
+Markov chain of ``smooth_cond`` run as a Kalman filter backwards in time that conditions on the observations
+(``_backward``, fenrir.py:86-259).  Both passes run on the device (``rk_solve_filter`` with
+``RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR`` + ``rk_fenrir_backward``); only B doubles come back.
+
+Same signature as the reference.  Extension: a leading batch axis on ``ode_init`` / ``prior_pars`` / ``**params``
+(observations are shared) returns an array (B,).  Restrictions of this build: ``kalman_type="standard"``, scalar
+observations per block (``obs_weight`` (n_obs, n_block, 1, n_bstate), ``obs_var`` (n_obs, n_block, 1, 1)).
+"""
+import ctypes as C
+import numpy as np
+from .. import _lib
+from ..solve import SolvePlan
+from .logpost import obs_index
+
+
+def fenrir(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars,
+           obs_data, obs_times, obs_weight, obs_var, kalman_type="standard", **params):
+    if kalman_type not in ("standard", "square-root"):
+        raise NotImplementedError                                   # fenrir.py:293-298
+    if kalman_type != "standard":
+        raise NotImplementedError("fenrir on the device: kalman_type='standard' only in this build")
+    obs = np.asarray(obs_data, dtype=np.float64)
+    D = np.asarray(obs_weight, dtype=np.float64)
+    Om = np.asarray(obs_var, dtype=np.float64)
+    if D.ndim != 4 or D.shape[2] != 1 or Om.shape != D.shape[:2] + (1, 1) or obs.shape != D.shape[:2] + (1,):
+        raise ValueError("fenrir: obs_data (n_obs, n_block, 1), obs_weight (n_obs, n_block, 1, n_bstate), obs_var "
+                         "(n_obs, n_block, 1, 1) -- scalar observations per block in this build")
+    plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
+                     store_pred=True, batch_minor=True, **params)
+    if D.shape[1:] != (plan.d, 1, plan.p):
+        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, 1, {plan.p})")
+    ind = obs_index(t_min, t_max, n_steps, obs_times)             # fenrir.py:118-120
+    if np.any(np.diff(ind) < 0):
+        raise ValueError("obs_times must be ascending")
+    plan.filter(key)
+    dev = plan.dev
+    d_obs, d_w, d_v, d_ind = (dev.to_device(np.ascontiguousarray(a)) for a in
+                              (obs[:, :, 0], D[:, :, 0, :], Om[:, :, 0, 0], ind.astype(np.int32)))
+    out = dev.empty((plan.B,))
+    _lib.check(dev.lib.rk_fenrir_backward(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(plan._out), d_obs.ptr,
+                                          d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), out.ptr))
+    ll = out.to_host()
+    return ll if plan.batched else float(ll[0])

@@ -135,3 +135,36 @@ def test_lockstep_pseudo_marginal_chain_on_device(ra):
         np.testing.assert_allclose(sd_state.logdensity, so_state.logdensity, rtol=1e-6, atol=1e-5)
         n_acc += int(info_d.is_accepted.sum())
     assert 0 < n_acc < 6 * C and np.all(np.isfinite(sd_state.logdensity))
+
+
+@pytest.mark.parametrize("name", ["kramer", "rodeo"])
+def test_fenrir_parity(ra, name):
+    """src/rodeo/inference/fenrir.py:261-327 on the device against the oracle restatement (itself pinned by the exact
+    Gaussian likelihood of a linear model, tests/test_oracle_fenrir.py): single trajectory and a batch, an observation
+    at the terminal time, one at time 0, several in between."""
+    from oracle import fenrir as ofen
+    s = _setup(ra, n_steps=60, t_max=3.0, n_obs=5)
+    g = {"kramer": ra.interrogate.interrogate_kramer, "rodeo": ra.interrogate.interrogate_rodeo}[name]
+    o = {"kramer": oi.interrogate_kramer, "rodeo": oi.interrogate_rodeo}[name]
+    n_obs = len(s["obs_times"])
+    y = s["Y"][:, :, None]                                                     # (n_obs, d, 1)
+    Dw = np.zeros((n_obs, 2, 1, 3)); Dw[..., 0] = 1.0
+    Om = np.full((n_obs, 2, 1, 1), 0.005)
+    args = (s["W"], s["x0"], 0.0, s["t_max"], s["N"])
+    val = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], y, s["obs_times"], Dw, Om,
+                              theta=s["theta"])
+    ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, o, s["prior"], y, s["obs_times"], Dw, Om, theta=s["theta"])
+    assert isinstance(val, float) and abs(val - ref) < 1e-7 * max(1.0, abs(ref)), (val, ref)
+    B = 7
+    th = s["theta"] * np.exp(0.05 * np.random.default_rng(1).standard_normal((B, 3)))
+    _, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    x0 = init(np.tile([-1., 1.], (B, 1)) + 0.05 * np.random.default_rng(2).standard_normal((B, 2)), 0., theta=th)
+    vb = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, s["W"], x0, 0.0, s["t_max"], s["N"], g, s["prior"], y,
+                             s["obs_times"], Dw, Om, theta=th)
+    rb = ofen.fenrir(None, odes.fitzhugh_nagumo, s["W"], x0, 0.0, s["t_max"], s["N"], o, s["prior"], y, s["obs_times"],
+                     Dw, Om, theta=th)
+    assert vb.shape == (B,)
+    np.testing.assert_allclose(vb, rb, rtol=1e-7, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], y, s["obs_times"], Dw, Om,
+                            kalman_type="cubature", theta=s["theta"])

@@ -1,0 +1,72 @@
+"""
+Pins oracle/fenrir.py: for a LINEAR ODE with the first-order (kramer) interrogation the solver's model is exactly
+linear Gaussian (z_n = W X_n - f(mu-) - J (X_n - mu-) = W X_n - f(X_n)), so Fenrir's value must equal the exact log p(y_{0:M} | z_{1:N} = 0), computed here by brute force from the
+joint Gaussian of all states (the construction of the reference's tests/gauss_markov.py, applied to this model).
+The reference has no fenrir test of its own.
+"""
+import numpy as np
+import pytest
+from scipy.stats import multivariate_normal
+from oracle import fenrir as ofen, odes, priors, interrogations as oi
+
+
+def _exact_loglik(W, x0, Q, R, N, t_min, t_max, forcing, obs_ind, D, Om, y):
+    """One block, state dim p; z_n = W X_n - (a^T X_n + forcing(t_n)) = 0 exactly; X_n = Q X_{n-1} + N(0, R)."""
+    p = len(x0)
+    # joint of (X_1..X_N): mean and covariance by propagation
+    mean = np.zeros((N + 1, p)); mean[0] = x0
+    cov = np.zeros((N + 1, N + 1, p, p))
+    for n in range(1, N + 1):
+        mean[n] = Q @ mean[n - 1]
+        cov[n, n] = Q @ cov[n - 1, n - 1] @ Q.T + R
+        for k in range(n):
+            cov[n, k] = Q @ cov[n - 1, k]
+            cov[k, n] = cov[n, k].T
+    mu = mean[1:].reshape(-1)
+    S = np.block([[cov[i, j] for j in range(1, N + 1)] for i in range(1, N + 1)])
+    ts = t_min + (t_max - t_min) * np.arange(1, N + 1) / N
+    # linear measurements z_n = Hz X_n - f_n with z = 0, and observations y_m = D X_m + noise
+    Hz = np.zeros((N, N * p)); fz = np.zeros(N)
+    for n in range(N):
+        Hz[n, n * p:(n + 1) * p] = W - forcing["a"]
+        fz[n] = forcing["f"](ts[n])
+    Hy = np.zeros((len(obs_ind), N * p))
+    for m, n in enumerate(obs_ind):
+        Hy[m, (n - 1) * p:n * p] = D
+    # condition on z = 0: X | z
+    Szz = Hz @ S @ Hz.T
+    K = S @ Hz.T @ np.linalg.inv(Szz)
+    mu_c = mu + K @ (fz - Hz @ mu)            # z = Hz X - fz = 0  <=>  Hz X = fz
+    S_c = S - K @ Hz @ S
+    my, Sy = Hy @ mu_c, Hy @ S_c @ Hy.T + Om * np.eye(len(obs_ind))
+    return multivariate_normal.logpdf(y, my, Sy, allow_singular=True)
+
+
+@pytest.mark.parametrize("itg", ["kramer"])
+def test_fenrir_equals_exact_gaussian_loglik_for_a_linear_ode(itg):
+    # x'' = sin(2t) - x  (docs/examples/higher_order.md), p = 3: W = [0, 0, 1], f = -X_0 + sin 2t
+    N, t_min, t_max, p = 10, 0.0, 1.0, 3
+    W = np.array([[[0.0, 0.0, 1.0]]])
+    x0 = np.array([[-1.0, 0.0, 1.0]])
+    Q, R = priors.ibm_init((t_max - t_min) / N, p, np.array([0.5]))
+    obs_times = np.array([0.2, 0.5, 1.0])
+    obs_ind = np.searchsorted(np.linspace(t_min, t_max, N + 1), obs_times)
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((3, 1, 1)) * 0.3 - 0.5
+    D = np.array([1.0, 0.0, 0.0])
+    obs_weight = np.tile(D[None, None, None, :], (3, 1, 1, 1))
+    Om = 0.05
+    obs_var = np.full((3, 1, 1, 1), Om)
+    g = {"schober": oi.interrogate_schober, "kramer": oi.interrogate_kramer}[itg]
+    val = ofen.fenrir(None, odes.higher_order, W, x0, t_min, t_max, N, g, (Q, R), y, obs_times, obs_weight, obs_var)
+    ref = _exact_loglik(W[0, 0], x0[0], Q[0], R[0], N, t_min, t_max,
+                        {"a": np.array([-1.0, 0.0, 0.0]), "f": lambda t: np.sin(2 * t)}, obs_ind, D, Om, y[:, 0, 0])
+    assert abs(val - ref) < 1e-8 * max(1.0, abs(ref)), (val, ref)
+
+
+def test_logpdf_drops_null_directions():
+    cov = np.diag([2.0, 0.0, 0.5])
+    x, m = np.array([1.0, 5.0, -1.0]), np.zeros(3)
+    val = ofen.multivariate_normal_logpdf(x, m, cov)
+    ref = multivariate_normal.logpdf([1.0, -1.0], [0, 0], np.diag([2.0, 0.5]))
+    assert abs(val - ref) < 1e-12
