@@ -1,4 +1,4 @@
-"""Per-kernel times of the headline configuration (C2) from the library's HIP-event profile; optional batch size."""
+"""Per-kernel times of the headline configuration (C2) from the library's HIP-event profile, solve_mv and filter-only streams; optional batch sizes as arguments."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rodeo_amd as ra
