@@ -315,6 +315,30 @@ def test_tile_path_short_horizons(ra, N):
     assert np.max(np.abs(x - xo)) < 1e-8
 
 
+def test_tile_path_huge_batch_64bit_offsets(ra):
+    """
+    A batch so large that one 16-step chunk of time rows spans more than 2 GiB (the backward consumer's buffer-store
+    window no longer fits and it takes its pointer path; every row offset needs 64 bits): 760,000 trajectories x 17
+    steps, checked on a few hundred trajectories at three time slices downloaded individually.
+    """
+    B, N, t_max = 760000, 17, 0.17
+    rng = np.random.default_rng(1)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.1 * rng.standard_normal((B, 3)))
+    x0v = np.array([-1., 1.]) + 0.1 * rng.standard_normal((B, 2))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    x0 = init(x0v, 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / N, 3, np.array([.1, .1]))
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, x0, 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
+    assert 15 * 2 * B * 96 + 384 > 2 ** 31
+    plan.mv(None)
+    idx = np.concatenate([np.arange(0, 40), np.arange(B - 40, B), rng.integers(0, B, 120)])
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, W, x0[idx], 0.0, t_max, N, oi.interrogate_kramer, prior, theta=theta[idx])
+    for n in (1, 9, N):
+        t = plan.var_state.slice0_host(n)                      # (B, d, 3, 4) tiles of time n
+        assert np.max(np.abs(t[idx][..., 3] - mo[:, n])) < 1e-10
+        assert np.max(np.abs(t[idx][..., :3] - vo[:, n])) <= 1e-9 * np.max(np.abs(vo[:, n]))
+
+
 def test_tile_path_higher_order_single_block(ra):
     """n_block = 1 through the tile path (4 trajectories per wave), p = 3: x'' = sin 2t - x with W = [0, 0, 1]."""
     from rodeo_amd import _lib
