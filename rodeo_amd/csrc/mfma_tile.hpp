@@ -13,7 +13,9 @@
 // so for registers X, Y, Z holding one matrix element per lane in D layout:   MF(X, Y, Z) = X^T Y + Z   per tile.
 // Latency 29 cycles through A/B, 21 through C; issue 16 cycles (profiles/r01_probe2_fp64_valu_mfma_latency.log).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 #include "linalg_small.hpp"
 
 namespace rk {

@@ -6,6 +6,8 @@
 // rk::AutoJac of csrc/dual.hpp for the Jacobian) and the kernel templates of solve_small_kernels.hpp are
 // instantiated for it at run time, once per (n_bstate, interrogation) actually used.
 #include <hip/hiprtc.h>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -32,13 +34,16 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
     char buf[512];
     (void)u;   // the user's type is aliased to rk::UserRhsT inside the translation unit (it may be a template-id)
     if (kind == 2) snprintf(buf, sizeof buf, "rk::interrogate_kernel<rk::UserRhsT, %d, %d>", P, itg);
+    else if (kind == 3) snprintf(buf, sizeof buf, "rk::fwd_tile3_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 3
+    else if (kind == 4) snprintf(buf, sizeof buf, "rk::fwd_tile4_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 4
     else snprintf(buf, sizeof buf, "rk::fwd_kernel<rk::UserRhsT, %d, %d, %s>", P, itg, kind == 1 ? "true" : "false");
     return buf;
 }
 
 // compile one instantiation; returns code object in `code` and the mangled name in `lowered`
 static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<char>& code, std::string& lowered) {
-    const std::string src = std::string("#include \"solve_small_kernels.hpp\"\n#include \"dual.hpp\"\nnamespace rk {\n") +
+    const std::string src = std::string("#include \"solve_small_kernels.hpp\"\n#include \"dual.hpp\"\n"
+                                        "#include \"solve_tile3_kernels.hpp\"\n#include \"solve_tile4_kernels.hpp\"\nnamespace rk {\n") +
                             u.source + "\nusing UserRhsT = " + u.type_name + ";\n}  // namespace rk\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rk_user_rhs.hip", kJitNumHeaders, kJitHeaderSources, kJitHeaderNames) !=
@@ -75,6 +80,23 @@ static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<c
     return RK_OK;
 }
 
+// compiled code objects, device independent: (rhs, P, itg, kind) -> (return code, code, lowered name).  A failed
+// compilation is remembered too (the tile kernels are tried first and simply do not exist for some right-hand sides).
+struct JitCode { int rc; std::vector<char> code; std::string lowered; std::string error; };
+static std::map<std::tuple<int, int, int, int>, JitCode> g_code;
+
+static const JitCode& jit_code_locked(int rhs_id, int P, int itg, int kind) {
+    const auto key = std::make_tuple(rhs_id, P, itg, kind);
+    auto it = g_code.find(key);
+    if (it == g_code.end()) {
+        JitCode c;
+        c.rc = jit_compile(g_rhs[rhs_id - RK_RHS_USER_BASE], P, itg, kind, c.code, c.lowered);
+        if (c.rc) c.error = rk_last_error();
+        it = g_code.emplace(key, std::move(c)).first;
+    }
+    return it->second;
+}
+
 static int jit_get(rk_handle h, int rhs_id, int P, int itg, int kind, hipFunction_t* fn) {
     std::lock_guard<std::mutex> lk(g_mu);
     const int idx = rhs_id - RK_RHS_USER_BASE;
@@ -82,16 +104,42 @@ static int jit_get(rk_handle h, int rhs_id, int P, int itg, int kind, hipFunctio
     const auto key = std::make_tuple(h->device, rhs_id, P, itg, kind);
     auto it = g_cache.find(key);
     if (it == g_cache.end()) {
-        std::vector<char> code;
-        std::string lowered;
-        int rc = jit_compile(g_rhs[idx], P, itg, kind, code, lowered);
-        if (rc) return rc;
+        const JitCode& c = jit_code_locked(rhs_id, P, itg, kind);
+        if (c.rc) { set_error("%s", c.error.c_str()); return c.rc; }
         JitEntry e;
-        RK_HIP(hipModuleLoadData(&e.mod, code.data()));
-        RK_HIP(hipModuleGetFunction(&e.fn, e.mod, lowered.c_str()));
+        RK_HIP(hipModuleLoadData(&e.mod, c.code.data()));
+        RK_HIP(hipModuleGetFunction(&e.fn, e.mod, c.lowered.c_str()));
         it = g_cache.emplace(key, e).first;
     }
     *fn = it->second.fn;
+    return RK_OK;
+}
+
+// Does the MFMA-tile forward kernel exist for this user right-hand side and configuration?  (It needs NDEP == 1 and a
+// block count the tile kernels support; decided by compiling it once -- cached -- so that rk_solve_layout and the
+// solve agree.)  which = 3 / 4 for n_bstate = 3 / 4.
+bool user_tile_available(const rk_solve_cfg* c, int which) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int idx = c->rhs_id - RK_RHS_USER_BASE;
+    if (idx < 0 || idx >= (int)g_rhs.size()) return false;
+    const int nb = g_rhs[idx].n_block;
+    if (c->n_block != nb || c->n_bmeas != 1 || c->kalman_type != RK_KALMAN_STANDARD) return false;
+    if (which == 3 ? (nb < 1 || nb > 2) : (nb < 1 || nb > 3)) return false;
+    const JitCode& jc = jit_code_locked(c->rhs_id, which, c->interrogate, which);
+    if (jc.rc && getenv("RK_JIT_VERBOSE")) fprintf(stderr, "[rk] tile kernel not available for user rhs %d (p = %d): %s\n", c->rhs_id, which, jc.error.c_str());
+    return jc.rc == RK_OK;
+}
+
+int user_forward_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int which) {
+    hipFunction_t fn;
+    int rc = jit_get(h, c->rhs_id, which, c->interrogate, which, &fn);
+    if (rc) return rc;
+    SolveArgs args = a;
+    void* params[] = {&args, &tiles};
+    const int tpw = (which == 4 && c->n_block == 3) ? 3 : 4;
+    LaunchTimer t(h, which == 3 ? "fwd_tile3_kernel<user>" : "fwd_tile4_kernel<user>");
+    RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B * c->n_block, tpw), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));
+    t.stop();
     return RK_OK;
 }
 

@@ -7,3 +7,12 @@
 #define RK_INTERROGATE_KRAMER     2
 #define RK_INTERROGATE_CHKREBTII  3
 #endif
+
+// Optional members of a right-hand side type (csrc/rhs.hpp): user-supplied types need not declare them.
+namespace rk {
+template <class...> using void_t_ = void;
+template <class R, class = void> struct rhs_has_tile_form { static constexpr bool value = false; };
+template <class R> struct rhs_has_tile_form<R, void_t_<decltype(R::HAS_TILE_FORM)>> { static constexpr bool value = R::HAS_TILE_FORM; };
+template <class R, class = void> struct rhs_has_tile3_form { static constexpr bool value = false; };
+template <class R> struct rhs_has_tile3_form<R, void_t_<decltype(R::HAS_TILE3_FORM)>> { static constexpr bool value = R::HAS_TILE3_FORM; };
+}  // namespace rk

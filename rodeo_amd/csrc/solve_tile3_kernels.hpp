@@ -1,0 +1,212 @@
+// Forward kernel of the p = 3 MFMA-tile path (solve_tile3.hip holds the description of the tile algebra), as a template
+// over the right-hand side: instantiated ahead of time for the built-in ODEs (solve_tile3.hip) and at run time by
+// hiprtc for user-supplied ones (rhs_jit.hip).  RTC-safe: no host code, no <hip/hip_runtime.h> under __HIPCC_RTC__.
+#pragma once
+#include "rk_enums.hpp"
+#include "kalman_small.hpp"
+#include "mfma_tile.hpp"
+#include "philox.hpp"
+#include "solve_args.hpp"
+
+namespace rk {
+
+constexpr int TILE_DOUBLES = 12;     // 3 rows x [Sigma(3) | mu] per (time step, tile)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct TileCoord {
+    int r, g, c;          // row, tile-in-wave, column
+    int tau;              // global tile index (clamped to a valid tile)
+    int b, blk;           // trajectory, block
+    bool valid;           // this lane's tile exists
+};
+
+template <int D>
+__device__ __forceinline__ TileCoord tile_coord(int wave, int lane, int n_tiles) {
+    TileCoord t;
+    t.r = lane >> 4; t.g = (lane >> 2) & 3; t.c = lane & 3;
+    const int tau = wave * 4 + t.g;
+    t.valid = tau < n_tiles;
+    t.tau = t.valid ? tau : n_tiles - 1;
+    t.b = t.tau / D; t.blk = t.tau - t.b * D;
+    return t;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+template <class RHS, int ITG>
+__global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __restrict__ tiles) {
+    constexpr int D = RHS::D, P = 3;
+    static_assert(D == 1 || D == 2, "tile path: n_block in {1, 2}");
+    static_assert(RHS::NDEP == 1, "tile path: right-hand sides that depend on X[b][0] only");
+    const int n_tiles = a.B * D;
+    const TileCoord tc = tile_coord<D>(blockIdx.x, threadIdx.x, n_tiles);
+    const int r = tc.r, c = tc.c, b = tc.b, blk = tc.blk;
+    const bool in3 = r < 3 && c < 3;
+
+    // per-lane constants in D layout
+    const double Qt = in3 ? ld(a.Q, ((size_t)blk * P + c) * P + r, a.Q_b, a.B, b) : ((r == 3 && c == 3) ? 1.0 : 0.0);
+    const double Qt0 = in3 ? Qt : 0.0;                 // Q~^T with the (3,3) one removed: MF(Qt0, U, .) has a zero row 3
+    const double Rt = in3 ? ld(a.R, ((size_t)blk * P + r) * P + c, a.R_b, a.B, b) : 0.0;
+    const double RtT = in3 ? ld(a.R, ((size_t)blk * P + c) * P + r, a.R_b, a.B, b) : 0.0;   // R~^T
+    const double Wr = r < 3 ? ld(a.W, (size_t)blk * P + r, a.W_b, a.B, b) : 0.0;          // W[k] at row k (all columns)
+    const double Y0 = r < 3 ? ld(a.Q, ((size_t)blk * P + 0) * P + r, a.Q_b, a.B, b) : 0.0; // Q[0][k] at row k
+    const double E0 = r == 0 ? 1.0 : 0.0;                                                  // selects row 0
+    const double e3r = r == 3 ? 1.0 : 0.0;
+    double th[RHS::NTHETA];
+#pragma unroll
+    for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
+    // Tile form of the right-hand side (rhs.hpp): f_b = k0 v + k1 v^3 + k2 v' + k3, J_b0 = k4 + k5 v^2 in the block's own
+    // and the other block's first state v, v'.  The measurement row X_w below (W_0 - J0 in row 0, W_r in rows 1 and 2,
+    // the offset a = J0 v - f in row 3) is then ONE cubic per lane with lane-dependent coefficients,
+    //     X_w = ((c3 v + c2) v + c1) v + (co v' + c0),
+    // four fused multiply-adds instead of f, J0, a and two selects (nine): every VALU instruction lengthens the
+    // step's dependent chain.  Same polynomials as interrogate.py:76-82, associated differently at rounding level.
+    double c3 = 0.0, c2 = 0.0, c1 = 0.0, co = 0.0, c0 = Wr;
+    if constexpr (rhs_has_tile_form<RHS>::value && D == 2) {
+        double tk[6];
+        RHS::tile_consts(blk, th, tk);
+        const bool jac = ITG == RK_INTERROGATE_KRAMER;
+        const double k4 = jac ? tk[4] : 0.0, k5 = jac ? tk[5] : 0.0;
+        if (r == 3) { c3 = k5 - tk[1]; c1 = k4 - tk[0]; co = -tk[2]; c0 = -tk[3]; }
+        if (r == 0) { c2 = -k5; c0 = Wr - k4; }
+    }
+    __shared__ double zbuf[4 * 16];                    // chkrebtii: z_0 of the next 16 steps for each of the 4 tiles
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+
+    // M_0 = [0 | ode_init ; 0 1]   (solve.py:53-54)
+    double M = r < 3 ? (c == 3 ? ld(a.x0, (size_t)blk * P + r, a.x0_b, a.B, b) : 0.0) : (c == 3 ? 1.0 : 0.0);
+    // lanes without a slot in the 3 x 4 tile: row 3, or tiles past the end
+    const bool st = tc.valid && r < 3;
+    const size_t tstride_all = (size_t)n_tiles * TILE_DOUBLES;
+    double* const dump = tiles + (size_t)(a.N + 1) * tstride_all + (size_t)blockIdx.x * 64;
+    dump[threadIdx.x] = r == 3 ? (c == 3 ? 1.0 : 0.0) : 0.0;       // row 3 = e_3 for the backward kernels' slot-less lanes
+    // In the loop every lane stores through a 384-byte buffer window on this wave's part of the time row (scalar base,
+    // no per-lane pointer arithmetic: every VALU instruction lengthens the dependent chain); slot-less lanes are out of
+    // range and dropped by the hardware.
+    const char* row = (const char*)(tiles + (size_t)blockIdx.x * 4 * TILE_DOUBLES);
+    const int bvoff = st ? (int)((tc.g * TILE_DOUBLES + r * 4 + c) * sizeof(double)) : (int)0x80000000;
+    auto store_row = [&](double v) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 4 * TILE_DOUBLES * 8, 0x00020000);
+        u32x2 bits;
+        __builtin_memcpy(&bits, &v, 8);
+        __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, bvoff, 0, 0);
+    };
+    store_row(M);
+
+    if constexpr (rhs_has_tile_form<RHS>::value && D == 2 && ITG != RK_INTERROGATE_CHKREBTII) {
+        // The headline path.  A step is ONE dependent chain for its wave (seven MFMAs, thirteen VALU instructions, one
+        // store), and with few trajectories (at most one wave per SIMD) its latency is the run time.  What was measured
+        // about that chain (profiles/r01_probe2/3/6/8/9*.log): nothing of the same wave overlaps an fp64 MFMA but another,
+        // independent MFMA; a dependent MFMA or any VALU instruction behind an MFMA waits its full 29 cycles; a dependent
+        // VALU operation costs about 7.  Hence: as few instructions as possible (merged cubic for X_w, cubic reciprocal
+        // step, buffer store), and the statement order below, which is the one hipcc's scheduler turns into the
+        // shortest stream (240 cycles per step; its choices for other source orders, and every order pinned with
+        // sched_barriers, measured 250-300).  A loop rotated to take U and the evaluation point off the chain with two
+        // more MFMAs per step measured 344.
+        // The order is pinned with empty asm statements that make an input of the next instruction "depend" on the result
+        // of the previous one: no instruction is emitted, the variables keep their registers, hipcc still inserts the
+        // wait states, and the stream no longer changes with unrelated edits (sched_barriers cost 12-24 cycles per
+        // step; of 220 random valid orders in profiles/r01_probe9_fwd_order_search.log this one was the fastest).
+#define RK_AFTER(in, res) asm("" : "+v"(in) : "v"(res))
+        for (int n = 0; n < a.N; ++n) {
+            double U = MF(M, Qt, 0.0);                              // (Q~ M)^T                         (standard.py:57-59)
+            RK_AFTER(M, U);
+            double B0 = MF(Y0, M, 0.0);                             // row 0 of Q~ M in every row: mu-_0 in column 3
+            RK_AFTER(U, B0);
+            double MpT = MF(Qt0, U, RtT);                           // M-^T with row 3 zeroed: the offset entry of X_w must not enter Z0
+            RK_AFTER(B0, MpT);
+            const double v_own = quad_bcast3(B0);                   // the point the ODE is evaluated at, X[b][0]
+            const double v_oth = pair_other_quad_uniform(v_own);
+            const double Xw = fma(fma(fma(c3, v_own, c2), v_own, c1), v_own, fma(co, v_oth, c0));
+            RK_AFTER(U, Xw);
+            double Mp = MF(U, Qt, Rt);                              // M- = Q~ M Q~^T + R~
+            RK_AFTER(MpT, Mp);
+            double Z0 = MF(MpT, Xw, 0.0);                           // Sigma- W~^T                      (standard.py:97)
+            RK_AFTER(Mp, Z0);
+            double WS = MF(Xw, Mp, 0.0);                            // [W~ Sigma- | W~ mu- + a]
+            RK_AFTER(Z0, WS);
+            double S = MF(Z0, Xw, 0.0);
+            RK_AFTER(WS, S);
+            if constexpr (ITG == RK_INTERROGATE_RODEO) S = S + S;   // var_meas = W Sigma- W^T (interrogate.py:110-113)
+            const double PW = Z0 * WS;
+            RK_AFTER(S, PW);
+            const double y0 = __builtin_amdgcn_rcp(S);
+            const double e = fma(-S, y0, 1.0);
+            const double y = fma(y0, fma(e, e, e), y0);             // 1 / S (linalg_small.hpp, fast_rcp_cubic)
+            M = fma(-PW, y, Mp);                                    // [Sigma- - K (W~ Sigma-) | mu- - K yhat]  (standard.py:98-102)
+            row += tstride_all * sizeof(double);
+            store_row(M);
+        }
+#undef RK_AFTER
+        return;
+    }
+    for (int n = 0; n < a.N; ++n) {
+        // ---- predict (standard.py:57-59): U = (Q~ M)^T, M- = Q~ M Q~^T + R~; B0 = row 0 of Q~ M in every row ----
+        // (a 4x4x4 fp64 MFMA blocks this wave's issue for ~17 cycles = 4 fp64 VALU ops, and nothing overlaps it --
+        //  profiles/r01_probe3_mfma_valu_serialize.log -- so the step is written with the fewest MFMAs: seven)
+        const double U = MF(M, Qt, 0.0);
+        double v_own;                                  // the point the ODE is evaluated at: X[b][0] of this tile's block
+        if constexpr (ITG != RK_INTERROGATE_CHKREBTII) v_own = quad_bcast3(MF(Y0, M, 0.0));   // mu-_0 in all 16 lanes
+        const double Mp = MF(U, Qt, Rt);
+        // exact transpose of M- (Q~ M^T Q~^T + R~^T) with its row 3 (= mu-^T) zeroed, so that the offset entry of X_w
+        // below does not enter Sigma- W~^T
+        const double MpT = MF(Qt0, U, RtT);
+        if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
+            // interrogate.py:22-34: x ~ N(mu-, Sigma-) with the lower factor; only x_0 = mu-_0 + sqrt(Sigma-_00) z_0
+            // reaches f (RHS::NDEP == 1).  The 16 lanes of a tile draw z_0 for 16 consecutive steps at once.
+            if ((n & 15) == 0) {
+                double z0, z1;
+                normal_pair(a.seed, traj, (uint32_t)(n + r * 4 + c), (uint32_t)blk, PURPOSE_INTERROGATE, 0u, z0, z1);
+                zbuf[tc.g * 16 + r * 4 + c] = z0;
+            }
+            const double zn = zbuf[tc.g * 16 + (n & 15)];
+            const double R0 = MF(E0, Mp, 0.0);         // row 0 of M- in every row: [Sigma-_00 .. | mu-_0]
+            const double s00 = quad_bcast0(R0);
+            v_own = fma(sqrt(s00 > 0.0 ? s00 : 0.0), zn, quad_bcast3(R0));
+        }
+        // ---- interrogation (interrogate.py): f and the block-diagonal Jacobian at v_own ----
+        const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
+        double Xw;      // X_w[k] (row form): W~_k = W_k - J_k for k < 3 (solve.py:79, interrogate.py:80), a = -f + J mu- at k = 3
+        if constexpr (rhs_has_tile_form<RHS>::value && D == 2) {
+            const double v_oth = pair_other_quad_uniform(v_own);        // v_own is uniform in each quad
+            Xw = fma(fma(fma(c3, v_own, c2), v_own, c1), v_own, fma(co, v_oth, c0));
+        } else {
+            double X[D][P];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb)
+#pragma unroll
+                for (int j = 0; j < P; ++j) X[bb][j] = 0.0;
+            if constexpr (D == 1) {
+                X[0][0] = v_own;
+            } else {
+                X[0][0] = pair_block0(v_own);
+                X[1][0] = pair_block1(v_own);
+            }
+            double f[D], J[D][P];
+            if constexpr (ITG == RK_INTERROGATE_KRAMER) {
+                RHS::template fjac<P>(X, t, th, f, J);
+            } else {
+                RHS::template f<P>(X, t, th, f);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+            }
+            double fb = f[0], J0 = J[0][0];
+            if constexpr (D == 2) { fb = blk == 0 ? f[0] : f[1]; J0 = blk == 0 ? J[0][0] : J[1][0]; }
+            const double a_meas = fma(J0, v_own, -fb);                  // mean_meas (interrogate.py:81-82)
+            Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));                    // rows: W_0 - J0, W_1, W_2, a
+        }
+        // ---- update (standard.py:93-102) ----
+        const double WS = MF(Xw, Mp, 0.0);                          // [W~ Sigma- | W~ mu- + a]   (column form)
+        const double Z0 = MF(MpT, Xw, 0.0);                         // Sigma- W~^T (standard.py:97; row form, 0 in row 3)
+        double S = MF(Z0, Xw, 0.0);
+        if constexpr (ITG == RK_INTERROGATE_RODEO || ITG == RK_INTERROGATE_CHKREBTII)
+            S = S + S;                                              // var_meas = W Sigma- W^T (interrogate.py:110-113, 26-29)
+        const double K = Z0 * fast_rcp(S);
+        M = fma(-K, WS, Mp);
+        row += tstride_all * sizeof(double);
+        store_row(M);
+    }
+}
+
+}  // namespace rk

@@ -1,0 +1,181 @@
+// Forward kernel of the p = 4 MFMA-tile path (see solve_tile4.hip), as a template over the right-hand side: built ahead
+// of time for the built-in ODEs and by hiprtc for user-supplied ones (rhs_jit.hip).  RTC-safe.
+#pragma once
+#include "rk_enums.hpp"
+#include "kalman_small.hpp"
+#include "mfma_tile.hpp"
+#include "solve_args.hpp"
+
+namespace rk {
+
+constexpr int T4_DOUBLES = 20;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int D>
+struct Tpw {                                     // tiles per wave
+    static constexpr int value = D == 3 ? 3 : 4;
+};
+
+struct T4Coord {
+    int r, g, c, tau, b, blk;
+    bool valid;
+};
+
+template <int D>
+__device__ __forceinline__ T4Coord t4_coord(int wave, int lane, int n_tiles) {
+    T4Coord t;
+    t.r = lane >> 4; t.g = (lane >> 2) & 3; t.c = lane & 3;
+    const int tau = wave * Tpw<D>::value + t.g;
+    t.valid = t.g < Tpw<D>::value && tau < n_tiles;
+    t.tau = t.valid ? tau : (wave * Tpw<D>::value < n_tiles ? wave * Tpw<D>::value : n_tiles - 1);
+    t.b = t.tau / D; t.blk = t.tau - t.b * D;
+    return t;
+}
+
+// value of block bb of this lane's trajectory, for every bb, given each tile's own value (tiles of one trajectory
+// are adjacent 4-lane banks of the DPP row): masked row rotations, no selects
+template <int D>
+__device__ __forceinline__ void gather_blocks(double own, double (&vals)[D]) {
+    if constexpr (D == 1) {
+        vals[0] = own;
+    } else if constexpr (D == 2) {
+        vals[0] = pair_block0(own);
+        vals[1] = pair_block1(own);
+    } else {
+        static_assert(D == 3, "gather_blocks: n_block in {1, 2, 3}");
+        // tiles g = 0, 1, 2 are blocks 0, 1, 2;  ror:4k moves a value k tiles up
+        vals[0] = dpp64_banks<0x128, 0x4>(dpp64_banks<0x124, 0x2>(own, own), own);   // g=1 <- g-1, g=2 <- g-2
+        vals[1] = dpp64_banks<0x124, 0x4>(dpp64_banks<0x12C, 0x1>(own, own), own);   // g=0 <- g+1, g=2 <- g-1
+        vals[2] = dpp64_banks<0x12C, 0x2>(dpp64_banks<0x128, 0x1>(own, own), own);   // g=0 <- g+2, g=1 <- g+1
+    }
+}
+
+template <int D>
+__device__ __forceinline__ double pick_block(const double (&v)[D], int blk) {
+    if constexpr (D == 1) return v[0];
+    else if constexpr (D == 2) return blk == 0 ? v[0] : v[1];
+    else return blk == 0 ? v[0] : (blk == 1 ? v[1] : v[2]);
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+template <class RHS, int ITG>
+__global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __restrict__ tiles) {
+    constexpr int D = RHS::D, P = 4;
+    static_assert(RHS::NDEP == 1, "tile path: right-hand sides that depend on X[b][0] only");
+    const int n_tiles = a.B * D;
+    const T4Coord tc = t4_coord<D>(blockIdx.x, threadIdx.x, n_tiles);
+    const int r = tc.r, c = tc.c, b = tc.b, blk = tc.blk;
+
+    const double Qt = ld(a.Q, ((size_t)blk * P + c) * P + r, a.Q_b, a.B, b);          // Q^T in D layout
+    const double Rt = ld(a.R, ((size_t)blk * P + r) * P + c, a.R_b, a.B, b);
+    const double RtT = ld(a.R, ((size_t)blk * P + c) * P + r, a.R_b, a.B, b);         // R^T in D layout
+    const double Wr = ld(a.W, (size_t)blk * P + r, a.W_b, a.B, b);                    // row form
+    const double Y0 = ld(a.Q, ((size_t)blk * P + 0) * P + r, a.Q_b, a.B, b);          // Q[0][k] at row k
+    const double E0 = r == 0 ? 1.0 : 0.0;
+    double th[RHS::NTHETA];
+#pragma unroll
+    for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
+
+    double S = 0.0;                                                                    // solve.py:54
+    double m = ld(a.x0, (size_t)blk * P + r, a.x0_b, a.B, b);                         // solve.py:53, row form
+    const size_t tstride_all = (size_t)n_tiles * T4_DOUBLES;
+    double* const dump = tiles + (size_t)(a.N + 1) * tstride_all + (size_t)blockIdx.x * 128;
+    const bool st_m = tc.valid && c == 0;
+    if constexpr (rhs_has_tile3_form<RHS>::value && D == 3) {
+        // Lorenz63-type right-hand sides (config C3) in hand-trimmed form, after fwd_tile3_kernel: every instruction of
+        // the wave lies on the step's dependent chain, so -- per-lane coefficients instead of three blocks + selects
+        // (the measurement row W~ = W - J is constant, the offset a = J mu- - f is a bilinear form of this block's and
+        // its neighbours' evaluation points, fetched with three plain DPP row rotations), cubic reciprocal step,
+        // buffer stores with a scalar row base (slot-less lanes dropped by the range check).
+        double kk[5];
+        RHS::tile3_consts(blk, th, kk);
+        const bool jac = ITG == RK_INTERROGATE_KRAMER;
+        const double c0 = jac ? 0.0 : -kk[0], c1 = -kk[1], c2 = -kk[2], c3 = -kk[3], c4 = -kk[4];   // a = -f + J0 own
+        const double Xw = fma(jac ? -kk[0] : 0.0, E0, Wr);          // W~ = W - J, row form (solve.py:79): constant
+        const char* row = (const char*)(tiles + (size_t)blockIdx.x * Tpw<D>::value * T4_DOUBLES);
+        const int voS = tc.valid ? (int)((tc.g * T4_DOUBLES + r * 4 + c) * sizeof(double)) : (int)0x80000000;
+        const int voM = st_m ? (int)((tc.g * T4_DOUBLES + 16 + r) * sizeof(double)) : (int)0x80000000;
+        auto store_row = [&](double vS, double vM) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, Tpw<D>::value * T4_DOUBLES * 8, 0x00020000);
+            u32x2 bS, bM;
+            __builtin_memcpy(&bS, &vS, 8);
+            __builtin_memcpy(&bM, &vM, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(bS, rsrc, voS, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(bM, rsrc, voM, 0, 0);
+        };
+        store_row(S, m);
+        for (int n = 0; n < a.N; ++n) {
+            const double U = MF(S, Qt, 0.0);
+            const double v_own = MF(Y0, m, 0.0);                      // (Q mu)_0 in all 16 lanes of the tile
+            const double mp = MF(Qt, m, 0.0);                         // Q mu, row form
+            const double SpT = MF(Qt, U, RtT);                        // exact transpose of S-: Q Sigma^T Q^T + R^T
+            const double Sp = MF(U, Qt, Rt);                          // Q Sigma Q^T + R
+            const double n1 = from_next_tile(v_own), p1 = from_prev_tile(v_own), p2 = dpp64<0x128>(v_own);
+            const double a_meas = fma(c4, p2 * p1, fma(c3, p1 * n1, fma(c2, p1, fma(c1, n1, c0 * v_own))));
+            const double Z = MF(SpT, Xw, 0.0);                        // Sigma- W~^T (standard.py:97), row form
+            const double WS = MF(Xw, Sp, 0.0);
+            const double yhat = MF(Xw, mp, a_meas);
+            double Sc = MF(Z, Xw, 0.0);
+            if constexpr (ITG == RK_INTERROGATE_RODEO) Sc = Sc + Sc;  // var_meas = W Sigma- W^T (interrogate.py:110-113)
+            const double K = -Z * fast_rcp_cubic(Sc);
+            S = fma(K, WS, Sp);
+            m = fma(K, yhat, mp);
+            row += tstride_all * sizeof(double);
+            store_row(S, m);
+        }
+        return;
+    }
+    double* oS = tc.valid ? tiles + (size_t)tc.tau * T4_DOUBLES + r * 4 + c : dump + threadIdx.x;
+    double* oM = st_m ? tiles + (size_t)tc.tau * T4_DOUBLES + 16 + r : dump + 64 + threadIdx.x;
+    const size_t sS = tc.valid ? tstride_all : 0, sM = st_m ? tstride_all : 0;
+    oS[0] = S;
+    oM[0] = m;
+
+    for (int n = 0; n < a.N; ++n) {
+        const double U = MF(S, Qt, 0.0);
+        const double v_own = MF(Y0, m, 0.0);                      // (Q mu)_0 in all 16 lanes of the tile
+        const double mp = MF(Qt, m, 0.0);                         // Q mu, row form
+        const double Sp = MF(U, Qt, Rt);                          // Q Sigma Q^T + R
+        const double SpT = MF(Qt, U, RtT);                        // its exact transpose: Q Sigma^T Q^T + R^T
+        // ---- interrogation (interrogate.py) ----
+        double X[D][P], vals[D];
+        gather_blocks<D>(v_own, vals);
+#pragma unroll
+        for (int bb = 0; bb < D; ++bb) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) X[bb][j] = 0.0;
+            X[bb][0] = vals[bb];
+        }
+        const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
+        double f[D], J[D][P];
+        if constexpr (ITG == RK_INTERROGATE_KRAMER) {
+            RHS::template fjac<P>(X, t, th, f, J);
+        } else {
+            RHS::template f<P>(X, t, th, f);
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb)
+#pragma unroll
+                for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+        }
+        double J0s[D];
+#pragma unroll
+        for (int bb = 0; bb < D; ++bb) J0s[bb] = J[bb][0];
+        const double fb = pick_block<D>(f, blk), J0 = pick_block<D>(J0s, blk);
+        const double a_meas = fma(J0, v_own, -fb);                // mean_meas = -f + J mu-   (interrogate.py:81-82)
+        const double Xw = fma(-J0, E0, Wr);                       // W~ = W - J, row form     (solve.py:79)
+        // ---- update (standard.py:93-102) ----
+        const double yhat = MF(Xw, mp, a_meas);
+        const double WS = MF(Xw, Sp, 0.0);
+        const double Z = MF(SpT, Xw, 0.0);                        // Sigma- W~^T (standard.py:97), row form
+        double Sc = MF(Z, Xw, 0.0);
+        if constexpr (ITG == RK_INTERROGATE_RODEO) Sc = Sc + Sc;  // var_meas = W Sigma- W^T (interrogate.py:110-113)
+        const double K = Z * fast_rcp(Sc);
+        S = fma(-K, WS, Sp);
+        m = fma(-K, yhat, mp);
+        oS += sS; oM += sM;
+        oS[0] = S;
+        oM[0] = m;
+    }
+}
+
+}  // namespace rk

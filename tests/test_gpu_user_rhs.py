@@ -70,3 +70,28 @@ def test_user_sir_autodiff_vs_oracle(ra):
     w1, m1, v1 = ra.interrogate.interrogate_kramer(None, sir, W, 0.3, mp, vp, theta=theta)
     w2, m2, v2 = oi.interrogate_kramer(None, o_ode, W, 0.3, mp, vp, theta=theta)
     np.testing.assert_allclose(w1, w2, rtol=1e-12, atol=1e-13); np.testing.assert_allclose(m1, m2, rtol=1e-12, atol=1e-12)
+
+
+def test_user_rhs_takes_the_tile_path_when_it_can(ra):
+    """User right-hand sides get the MFMA-tile forward kernels by hiprtc when the tile path supports their shape
+    (p = 3 with <= 2 blocks, p = 4 with <= 3 blocks, NDEP == 1); otherwise the lane-per-trajectory kernels."""
+    from rodeo_amd import _lib
+    my = ra.ode.from_source("MyFitz", FN_SRC, 2, (("theta", 3),), ra.ode.fitzhugh_nagumo._host_fun, name="myfitz_tile")
+    theta = np.array([.2, .2, 3.])
+    for p, lay in ((3, _lib.LAYOUT_TILE3), (4, _lib.LAYOUT_TILE4), (5, _lib.LAYOUT_BATCH_MINOR)):
+        W, init = ra.utils.first_order_pad(my, 2, p)
+        x0 = init(np.array([-1., 1.]), 0.0, theta=theta)
+        prior = ra.ibm_init(0.05, p, np.array([.1, .1]))
+        plan = ra.SolvePlan(my, W, x0, 0., 2., 40, ra.interrogate.interrogate_kramer, prior, theta=theta)
+        plan.mv(None)
+        assert plan.layout == lay
+        m, v = plan.state_host()
+        mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, W, x0, 0., 2., 40, oi.interrogate_kramer, prior, theta=theta)
+        assert np.max(np.abs(m - mo)) < 1e-9 * max(1.0, np.max(np.abs(mo)))
+    sir = ra.ode.from_source("AutoJac<Sir3>", SEIR_SRC, 3, (("theta", 2),), sir_host, name="sir3_tile")
+    W, init = ra.utils.first_order_pad(sir, 3, 3)
+    x0 = init(np.array([0.95, 0.05, 0.0]), 0.0, theta=np.array([1.5, 0.4]))
+    plan = ra.SolvePlan(sir, W, x0, 0., 2., 40, ra.interrogate.interrogate_kramer, ra.ibm_init(0.05, 3, np.array([.1] * 3)),
+                        theta=np.array([1.5, 0.4]))
+    plan.mv(None)
+    assert plan.layout == _lib.LAYOUT_BATCH_MINOR            # three blocks at p = 3: no tile kernel, generic path
