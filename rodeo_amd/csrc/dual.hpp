@@ -116,6 +116,27 @@ struct AutoJac {
             for (int j = 0; j < P; ++j) J[b][j] = od[b].d[j];
         }
     }
+    // What the MFMA-tile kernels need (NDEP == 1, every lane works for ONE block): f_blk and d f_blk / d X[blk][0] from a
+    // single evaluation with one dual direction, instead of D evaluations with P directions each.
+    static constexpr bool HAS_FJAC0 = true;
+    template <int P>
+    __device__ __forceinline__ static void fjac0_block(const double (&X)[D][P], double t, const double (&th)[NTHETA],
+                                                       int blk, double& fb, double& J0) {
+        Dual<1> Xd[D][P], od[D];
+#pragma unroll
+        for (int bb = 0; bb < D; ++bb) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) Xd[bb][j] = Dual<1>(X[bb][j]);
+            Xd[bb][0].d[0] = bb == blk ? 1.0 : 0.0;
+        }
+        U::template rhs<Dual<1>, P>(Xd, t, th, od);
+        fb = od[0].v; J0 = od[0].d[0];
+#pragma unroll
+        for (int bb = 1; bb < D; ++bb) {
+            fb = bb == blk ? od[bb].v : fb;
+            J0 = bb == blk ? od[bb].d[0] : J0;
+        }
+    }
 };
 
 }  // namespace rk

@@ -15,4 +15,6 @@ template <class R, class = void> struct rhs_has_tile_form { static constexpr boo
 template <class R> struct rhs_has_tile_form<R, void_t_<decltype(R::HAS_TILE_FORM)>> { static constexpr bool value = R::HAS_TILE_FORM; };
 template <class R, class = void> struct rhs_has_tile3_form { static constexpr bool value = false; };
 template <class R> struct rhs_has_tile3_form<R, void_t_<decltype(R::HAS_TILE3_FORM)>> { static constexpr bool value = R::HAS_TILE3_FORM; };
+template <class R, class = void> struct rhs_has_fjac0 { static constexpr bool value = false; };
+template <class R> struct rhs_has_fjac0<R, void_t_<decltype(R::HAS_FJAC0)>> { static constexpr bool value = R::HAS_FJAC0; };
 }  // namespace rk

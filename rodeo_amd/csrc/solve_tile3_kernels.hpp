@@ -181,18 +181,23 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
                 X[0][0] = pair_block0(v_own);
                 X[1][0] = pair_block1(v_own);
             }
-            double f[D], J[D][P];
-            if constexpr (ITG == RK_INTERROGATE_KRAMER) {
-                RHS::template fjac<P>(X, t, th, f, J);
+            double fb, J0;
+            if constexpr (ITG == RK_INTERROGATE_KRAMER && rhs_has_fjac0<RHS>::value) {
+                RHS::template fjac0_block<P>(X, t, th, blk, fb, J0);    // one evaluation, one dual direction (dual.hpp)
             } else {
-                RHS::template f<P>(X, t, th, f);
+                double f[D], J[D][P];
+                if constexpr (ITG == RK_INTERROGATE_KRAMER) {
+                    RHS::template fjac<P>(X, t, th, f, J);
+                } else {
+                    RHS::template f<P>(X, t, th, f);
 #pragma unroll
-                for (int bb = 0; bb < D; ++bb)
+                    for (int bb = 0; bb < D; ++bb)
 #pragma unroll
-                    for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+                        for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+                }
+                fb = f[0]; J0 = J[0][0];
+                if constexpr (D == 2) { fb = blk == 0 ? f[0] : f[1]; J0 = blk == 0 ? J[0][0] : J[1][0]; }
             }
-            double fb = f[0], J0 = J[0][0];
-            if constexpr (D == 2) { fb = blk == 0 ? f[0] : f[1]; J0 = blk == 0 ? J[0][0] : J[1][0]; }
             const double a_meas = fma(J0, v_own, -fb);                  // mean_meas (interrogate.py:81-82)
             Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));                    // rows: W_0 - J0, W_1, W_2, a
         }
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         double S = MF(Z0, Xw, 0.0);
         if constexpr (ITG == RK_INTERROGATE_RODEO || ITG == RK_INTERROGATE_CHKREBTII)
             S = S + S;                                              // var_meas = W Sigma- W^T (interrogate.py:110-113, 26-29)
-        const double K = Z0 * fast_rcp(S);
+        const double K = Z0 * fast_rcp_cubic(S);
         M = fma(-K, WS, Mp);
         row += tstride_all * sizeof(double);
         store_row(M);

@@ -147,20 +147,25 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
             X[bb][0] = vals[bb];
         }
         const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
-        double f[D], J[D][P];
-        if constexpr (ITG == RK_INTERROGATE_KRAMER) {
-            RHS::template fjac<P>(X, t, th, f, J);
+        double fb, J0;
+        if constexpr (ITG == RK_INTERROGATE_KRAMER && rhs_has_fjac0<RHS>::value) {
+            RHS::template fjac0_block<P>(X, t, th, blk, fb, J0);    // one evaluation, one dual direction (dual.hpp)
         } else {
-            RHS::template f<P>(X, t, th, f);
+            double f[D], J[D][P];
+            if constexpr (ITG == RK_INTERROGATE_KRAMER) {
+                RHS::template fjac<P>(X, t, th, f, J);
+            } else {
+                RHS::template f<P>(X, t, th, f);
 #pragma unroll
-            for (int bb = 0; bb < D; ++bb)
+                for (int bb = 0; bb < D; ++bb)
 #pragma unroll
-                for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+                    for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+            }
+            double J0s[D];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) J0s[bb] = J[bb][0];
+            fb = pick_block<D>(f, blk); J0 = pick_block<D>(J0s, blk);
         }
-        double J0s[D];
-#pragma unroll
-        for (int bb = 0; bb < D; ++bb) J0s[bb] = J[bb][0];
-        const double fb = pick_block<D>(f, blk), J0 = pick_block<D>(J0s, blk);
         const double a_meas = fma(J0, v_own, -fb);                // mean_meas = -f + J mu-   (interrogate.py:81-82)
         const double Xw = fma(-J0, E0, Wr);                       // W~ = W - J, row form     (solve.py:79)
         // ---- update (standard.py:93-102) ----
@@ -169,7 +174,7 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
         const double Z = MF(SpT, Xw, 0.0);                        // Sigma- W~^T (standard.py:97), row form
         double Sc = MF(Z, Xw, 0.0);
         if constexpr (ITG == RK_INTERROGATE_RODEO) Sc = Sc + Sc;  // var_meas = W Sigma- W^T (interrogate.py:110-113)
-        const double K = Z * fast_rcp(Sc);
+        const double K = Z * fast_rcp_cubic(Sc);
         S = fma(-K, WS, Sp);
         m = fma(-K, yhat, mp);
         oS += sS; oM += sM;
