@@ -63,6 +63,46 @@ __device__ __forceinline__ double quad_bcast0(double x) { return dpp64<0x00>(x);
 __device__ __forceinline__ double from_prev_tile(double x) { return dpp64<0x124>(x); }   // row_ror:4
 __device__ __forceinline__ double from_next_tile(double x) { return dpp64<0x12C>(x); }   // row_ror:12
 
+// ---- the blocks of one trajectory inside a wave (forward kernels) --------------------------------------------------
+// A forward wave carries whole trajectories: with n_block = D the tiles g = 0..TPW-1 of a wave are 4 / D trajectories
+// (D = 1, 2, 4) or the three blocks of one (D = 3, tile slot 3 idles).
+template <int D>
+struct Tpw {                                     // tiles per forward wave
+    static constexpr int value = D == 3 ? 3 : 4;
+};
+
+// value of block bb of this lane's trajectory, for every bb, given each tile's own value (tiles of one trajectory
+// are adjacent 4-lane banks of the DPP row): masked row rotations, no selects
+template <int D>
+__device__ __forceinline__ void gather_blocks(double own, double (&vals)[D]) {
+    if constexpr (D == 1) {
+        vals[0] = own;
+    } else if constexpr (D == 2) {
+        vals[0] = pair_block0(own);
+        vals[1] = pair_block1(own);
+    } else if constexpr (D == 3) {
+        // tiles g = 0, 1, 2 are blocks 0, 1, 2;  ror:4k moves a value k tiles up
+        vals[0] = dpp64_banks<0x128, 0x4>(dpp64_banks<0x124, 0x2>(own, own), own);   // g=1 <- g-1, g=2 <- g-2
+        vals[1] = dpp64_banks<0x124, 0x4>(dpp64_banks<0x12C, 0x1>(own, own), own);   // g=0 <- g+1, g=2 <- g-1
+        vals[2] = dpp64_banks<0x12C, 0x2>(dpp64_banks<0x128, 0x1>(own, own), own);   // g=0 <- g+2, g=1 <- g+1
+    } else {
+        static_assert(D == 4, "gather_blocks: n_block in {1, 2, 3, 4}");
+        // block k's value goes to tile g by a rotation of (g - k) tiles: one masked move per distance
+        vals[0] = dpp64_banks<0x12C, 0x8>(dpp64_banks<0x128, 0x4>(dpp64_banks<0x124, 0x2>(own, own), own), own);
+        vals[1] = dpp64_banks<0x128, 0x8>(dpp64_banks<0x124, 0x4>(dpp64_banks<0x12C, 0x1>(own, own), own), own);
+        vals[2] = dpp64_banks<0x124, 0x8>(dpp64_banks<0x12C, 0x2>(dpp64_banks<0x128, 0x1>(own, own), own), own);
+        vals[3] = dpp64_banks<0x12C, 0x4>(dpp64_banks<0x128, 0x2>(dpp64_banks<0x124, 0x1>(own, own), own), own);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ double pick_block(const double (&v)[D], int blk) {
+    if constexpr (D == 1) return v[0];
+    else if constexpr (D == 2) return blk == 0 ? v[0] : v[1];
+    else if constexpr (D == 3) return blk == 0 ? v[0] : (blk == 1 ? v[1] : v[2]);
+    else return blk < 2 ? (blk == 0 ? v[0] : v[1]) : (blk == 2 ? v[2] : v[3]);
+}
+
 // ---- LDS hand-off swizzles of the backward kernels (producer lanes: one per item; consumer lanes: tile elements) ----
 // Slot (0..15, in doubles) of element (r, c) inside a 128-byte hand-off tile of item (s, g).  Two access patterns
 // must both be free of LDS bank conflicts (the tiles of all items start at the same bank):

@@ -124,7 +124,7 @@ bool user_tile_available(const rk_solve_cfg* c, int which) {
     if (idx < 0 || idx >= (int)g_rhs.size()) return false;
     const int nb = g_rhs[idx].n_block;
     if (c->n_block != nb || c->n_bmeas != 1 || c->kalman_type != RK_KALMAN_STANDARD) return false;
-    if (which == 3 ? (nb < 1 || nb > 2) : (nb < 1 || nb > 3)) return false;
+    if (nb < 1 || nb > 4) return false;                          // the blocks of a trajectory share a wave
     const JitCode& jc = jit_code_locked(c->rhs_id, which, c->interrogate, which);
     if (jc.rc && getenv("RK_JIT_VERBOSE")) fprintf(stderr, "[rk] tile kernel not available for user rhs %d (p = %d): %s\n", c->rhs_id, which, jc.error.c_str());
     return jc.rc == RK_OK;
@@ -136,7 +136,7 @@ int user_forward_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, do
     if (rc) return rc;
     SolveArgs args = a;
     void* params[] = {&args, &tiles};
-    const int tpw = (which == 4 && c->n_block == 3) ? 3 : 4;
+    const int tpw = c->n_block == 3 ? 3 : 4;
     LaunchTimer t(h, which == 3 ? "fwd_tile3_kernel<user>" : "fwd_tile4_kernel<user>");
     RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B * c->n_block, tpw), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));
     t.stop();

@@ -1,4 +1,4 @@
-// MFMA-tile solver kernels for n_bstate = 3, n_bmeas = 1, n_block in {1, 2}: the headline FitzHugh-Nagumo path.
+// MFMA-tile solver kernels for n_bstate = 3, n_bmeas = 1, n_block <= 4: the headline FitzHugh-Nagumo path.
 //
 //   src/rodeo/solve.py:31-122   _solve_filter -> fwd_tile3_kernel      one wave = 4 (trajectory, block) tiles
 //   src/rodeo/solve.py:257-301  solve_mv      -> bwd_mv_tile3_kernel   producer wave (gain, time-parallel)
@@ -176,14 +176,14 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
         __builtin_amdgcn_s_setprio(3);      // the dependent chain is the critical path: win issue arbitration on this SIMD
         const int r = tc.r, g = tc.g, c = tc.c, idx = r * 4 + c;
         const bool st = tc.valid && r < 3;
-        // lanes without a slot (row 3, tiles past the end) read and write the scratch tail with stride 0: row 3 of
-        // every tile is e_3 there (stored by the forward kernel and re-stored here), so no masking is needed
+        // lanes without a slot (row 3, tiles past the end) write the scratch tail with stride 0 in the pointer path
         double* base = st ? tiles + (size_t)tc.tau * TILE_DOUBLES + idx : dump + lane;
         const size_t ostride = st ? tstride : 0;
         int roff[4];                                                // per-lane LDS byte offsets for s & 3 = 0..3
 #pragma unroll
         for (int k = 0; k < 4; ++k) roff[k] = lds_byte(k, g, 0, idx) - k * 4 * ITEM_BYTES;
-        double Ms = base[(size_t)a.N * ostride];                    // carry = filt[N]  (solve.py:279-282)
+        // carry = filt[N] (solve.py:279-282); lanes without a slot hold row 3 = e_3 of the augmented tile (or zeros)
+        double Ms = st ? base[(size_t)a.N * ostride] : ((r == 3 && c == 3) ? 1.0 : 0.0);
         // full chunks store with a scalar row pointer + this lane's byte offset in the tile-wave's 384 bytes
         const char* const wave_rows = (const char*)(tiles + (size_t)tw * 4 * TILE_DOUBLES);
         const size_t row_bytes = tstride * sizeof(double);
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(256) bwd_sim_tile3_kernel(SolveArgs a, double*
 // per wave or more waves per workgroup change nothing (measured, round 1) -- only more trajectories raise throughput.
 template <class RHS>
 static int launch_fwd_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles) {
-    const dim3 grid(div_up(a.B * RHS::D, 4)), block(64);
+    const dim3 grid(div_up(a.B * RHS::D, Tpw<RHS::D>::value)), block(64);
     LaunchTimer t(h, "fwd_tile3_kernel");
     switch (c->interrogate) {
         case RK_INTERROGATE_KRAMER:
@@ -469,6 +469,7 @@ bool tile3_supported(const rk_solve_cfg* c, int mode) {
     if (c->kalman_type != RK_KALMAN_STANDARD || c->n_bstate != 3 || c->n_bmeas != 1) return false;
     if (c->interrogate < RK_INTERROGATE_RODEO || c->interrogate > RK_INTERROGATE_CHKREBTII) return false;
     if (c->rhs_id == RK_RHS_FITZHUGH_NAGUMO) return c->n_block == 2;
+    if (c->rhs_id == RK_RHS_LORENZ63) return c->n_block == 3;
     if (c->rhs_id == RK_RHS_HIGHER_ORDER) return c->n_block == 1;
     if (is_user_rhs(c->rhs_id)) return user_tile_available(c, 3);       // hiprtc build of fwd_tile3_kernel (rhs_jit.hip)
     return false;
@@ -477,6 +478,7 @@ bool tile3_supported(const rk_solve_cfg* c, int mode) {
 int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode) {
     int rc;
     if (c->rhs_id == RK_RHS_FITZHUGH_NAGUMO) rc = launch_fwd_tile<FitzHughNagumo>(h, c, a, tiles);
+    else if (c->rhs_id == RK_RHS_LORENZ63) rc = launch_fwd_tile<Lorenz63>(h, c, a, tiles);
     else if (is_user_rhs(c->rhs_id)) rc = user_forward_tile(h, c, a, tiles, 3);
     else rc = launch_fwd_tile<HigherOrder>(h, c, a, tiles);
     if (rc || mode == RK_MODE_FILTER) return rc;

@@ -20,13 +20,14 @@ struct TileCoord {
     bool valid;           // this lane's tile exists
 };
 
-template <int D>
+// TPW tiles per wave: 4 in the backward kernels (the flat tile array), Tpw<D> in the forward kernel (whole trajectories)
+template <int D, int TPW = 4>
 __device__ __forceinline__ TileCoord tile_coord(int wave, int lane, int n_tiles) {
     TileCoord t;
     t.r = lane >> 4; t.g = (lane >> 2) & 3; t.c = lane & 3;
-    const int tau = wave * 4 + t.g;
-    t.valid = tau < n_tiles;
-    t.tau = t.valid ? tau : n_tiles - 1;
+    const int tau = wave * TPW + t.g;
+    t.valid = t.g < TPW && tau < n_tiles;
+    t.tau = t.valid ? tau : (wave * TPW < n_tiles ? wave * TPW : n_tiles - 1);     // an idle slot repeats the wave's first tile
     t.b = t.tau / D; t.blk = t.tau - t.b * D;
     return t;
 }
@@ -34,11 +35,11 @@ __device__ __forceinline__ TileCoord tile_coord(int wave, int lane, int n_tiles)
 // ---- forward ---------------------------------------------------------------------------------------------------
 template <class RHS, int ITG>
 __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __restrict__ tiles) {
-    constexpr int D = RHS::D, P = 3;
-    static_assert(D == 1 || D == 2, "tile path: n_block in {1, 2}");
+    constexpr int D = RHS::D, P = 3, TPW = Tpw<D>::value;
+    static_assert(D >= 1 && D <= 4, "tile path: n_block in 1..4 (the blocks of a trajectory share a wave)");
     static_assert(RHS::NDEP == 1, "tile path: right-hand sides that depend on X[b][0] only");
     const int n_tiles = a.B * D;
-    const TileCoord tc = tile_coord<D>(blockIdx.x, threadIdx.x, n_tiles);
+    const TileCoord tc = tile_coord<D, TPW>(blockIdx.x, threadIdx.x, n_tiles);
     const int r = tc.r, c = tc.c, b = tc.b, blk = tc.blk;
     const bool in3 = r < 3 && c < 3;
 
@@ -77,15 +78,13 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     // lanes without a slot in the 3 x 4 tile: row 3, or tiles past the end
     const bool st = tc.valid && r < 3;
     const size_t tstride_all = (size_t)n_tiles * TILE_DOUBLES;
-    double* const dump = tiles + (size_t)(a.N + 1) * tstride_all + (size_t)blockIdx.x * 64;
-    dump[threadIdx.x] = r == 3 ? (c == 3 ? 1.0 : 0.0) : 0.0;       // row 3 = e_3 for the backward kernels' slot-less lanes
-    // In the loop every lane stores through a 384-byte buffer window on this wave's part of the time row (scalar base,
-    // no per-lane pointer arithmetic: every VALU instruction lengthens the dependent chain); slot-less lanes are out of
+    // In the loop every lane stores through a buffer window on this wave's part of the time row (scalar base, no
+    // per-lane pointer arithmetic: every VALU instruction lengthens the dependent chain); slot-less lanes are out of
     // range and dropped by the hardware.
-    const char* row = (const char*)(tiles + (size_t)blockIdx.x * 4 * TILE_DOUBLES);
+    const char* row = (const char*)(tiles + (size_t)blockIdx.x * TPW * TILE_DOUBLES);
     const int bvoff = st ? (int)((tc.g * TILE_DOUBLES + r * 4 + c) * sizeof(double)) : (int)0x80000000;
     auto store_row = [&](double v) {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 4 * TILE_DOUBLES * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, TPW * TILE_DOUBLES * 8, 0x00020000);
         u32x2 bits;
         __builtin_memcpy(&bits, &v, 8);
         __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, bvoff, 0, 0);
@@ -175,11 +174,11 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
             for (int bb = 0; bb < D; ++bb)
 #pragma unroll
                 for (int j = 0; j < P; ++j) X[bb][j] = 0.0;
-            if constexpr (D == 1) {
-                X[0][0] = v_own;
-            } else {
-                X[0][0] = pair_block0(v_own);
-                X[1][0] = pair_block1(v_own);
+            {
+                double vals[D];
+                gather_blocks<D>(v_own, vals);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) X[bb][0] = vals[bb];
             }
             double fb, J0;
             if constexpr (ITG == RK_INTERROGATE_KRAMER && rhs_has_fjac0<RHS>::value) {
@@ -195,8 +194,10 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
 #pragma unroll
                         for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
                 }
-                fb = f[0]; J0 = J[0][0];
-                if constexpr (D == 2) { fb = blk == 0 ? f[0] : f[1]; J0 = blk == 0 ? J[0][0] : J[1][0]; }
+                double J0s[D];
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) J0s[bb] = J[bb][0];
+                fb = pick_block<D>(f, blk); J0 = pick_block<D>(J0s, blk);
             }
             const double a_meas = fma(J0, v_own, -fb);                  // mean_meas (interrogate.py:81-82)
             Xw = fma(-J0, E0, fma(a_meas, e3r, Wr));                    // rows: W_0 - J0, W_1, W_2, a

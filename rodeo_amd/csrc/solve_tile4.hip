@@ -1,4 +1,4 @@
-// MFMA-tile solver kernels for n_bstate = 4, n_bmeas = 1, n_block in {1, 2, 3}: BASELINE config 3 (Lorenz63) and
+// MFMA-tile solver kernels for n_bstate = 4, n_bmeas = 1, n_block <= 4: BASELINE config 3 (Lorenz63) and
 // the second-order example of docs/examples/higher_order.md.  Same machinery as solve_tile3.hip (read that header
 // first); with p = 4 the 4 x 4 tile is filled by Sigma, so the mean travels as a second per-lane value in
 // "row form" (lane (r, g, c) holds mu_r for every c):
@@ -287,7 +287,8 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     LaunchTimer t(h, "bwd_mv_tile4_kernel");
     if (a.D == 1) hipLaunchKernelGGL((bwd_mv_tile4_kernel<1>), grid, block, 0, h->stream, a, tiles);
     else if (a.D == 2) hipLaunchKernelGGL((bwd_mv_tile4_kernel<2>), grid, block, 0, h->stream, a, tiles);
-    else hipLaunchKernelGGL((bwd_mv_tile4_kernel<3>), grid, block, 0, h->stream, a, tiles);
+    else if (a.D == 3) hipLaunchKernelGGL((bwd_mv_tile4_kernel<3>), grid, block, 0, h->stream, a, tiles);
+    else hipLaunchKernelGGL((bwd_mv_tile4_kernel<4>), grid, block, 0, h->stream, a, tiles);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

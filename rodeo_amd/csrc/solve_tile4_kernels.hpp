@@ -11,11 +11,6 @@ namespace rk {
 constexpr int T4_DOUBLES = 20;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-template <int D>
-struct Tpw {                                     // tiles per wave
-    static constexpr int value = D == 3 ? 3 : 4;
-};
-
 struct T4Coord {
     int r, g, c, tau, b, blk;
     bool valid;
@@ -30,31 +25,6 @@ __device__ __forceinline__ T4Coord t4_coord(int wave, int lane, int n_tiles) {
     t.tau = t.valid ? tau : (wave * Tpw<D>::value < n_tiles ? wave * Tpw<D>::value : n_tiles - 1);
     t.b = t.tau / D; t.blk = t.tau - t.b * D;
     return t;
-}
-
-// value of block bb of this lane's trajectory, for every bb, given each tile's own value (tiles of one trajectory
-// are adjacent 4-lane banks of the DPP row): masked row rotations, no selects
-template <int D>
-__device__ __forceinline__ void gather_blocks(double own, double (&vals)[D]) {
-    if constexpr (D == 1) {
-        vals[0] = own;
-    } else if constexpr (D == 2) {
-        vals[0] = pair_block0(own);
-        vals[1] = pair_block1(own);
-    } else {
-        static_assert(D == 3, "gather_blocks: n_block in {1, 2, 3}");
-        // tiles g = 0, 1, 2 are blocks 0, 1, 2;  ror:4k moves a value k tiles up
-        vals[0] = dpp64_banks<0x128, 0x4>(dpp64_banks<0x124, 0x2>(own, own), own);   // g=1 <- g-1, g=2 <- g-2
-        vals[1] = dpp64_banks<0x124, 0x4>(dpp64_banks<0x12C, 0x1>(own, own), own);   // g=0 <- g+1, g=2 <- g-1
-        vals[2] = dpp64_banks<0x12C, 0x2>(dpp64_banks<0x128, 0x1>(own, own), own);   // g=0 <- g+2, g=1 <- g+1
-    }
-}
-
-template <int D>
-__device__ __forceinline__ double pick_block(const double (&v)[D], int blk) {
-    if constexpr (D == 1) return v[0];
-    else if constexpr (D == 2) return blk == 0 ? v[0] : v[1];
-    else return blk == 0 ? v[0] : (blk == 1 ? v[1] : v[2]);
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------

@@ -94,4 +94,79 @@ def test_user_rhs_takes_the_tile_path_when_it_can(ra):
     plan = ra.SolvePlan(sir, W, x0, 0., 2., 40, ra.interrogate.interrogate_kramer, ra.ibm_init(0.05, 3, np.array([.1] * 3)),
                         theta=np.array([1.5, 0.4]))
     plan.mv(None)
-    assert plan.layout == _lib.LAYOUT_BATCH_MINOR            # three blocks at p = 3: no tile kernel, generic path
+    assert plan.layout == _lib.LAYOUT_TILE3                  # three blocks at p = 3: one trajectory per wave
+
+
+SEIR4_SRC = r"""
+// four compartments (S, E, I, R), scalar-generic
+struct Seir4 {
+    static constexpr int D = 4;
+    static constexpr int NTHETA = 3;
+    static constexpr int NDEP = 1;
+    template <class T, int P>
+    __device__ __forceinline__ static void rhs(const T (&X)[D][P], double t, const double (&th)[NTHETA], T (&out)[D]) {
+        const T S = X[0][0], E = X[1][0], I = X[2][0], R = X[3][0];
+        const double beta = th[0], kappa = th[1], gamma = th[2];
+        out[0] = -beta * S * I;
+        out[1] = beta * S * I - kappa * E;
+        out[2] = kappa * E - gamma * I;
+        out[3] = gamma * I + 0.0 * R;
+    }
+};
+"""
+
+
+def _seir_host(X, t, theta):
+    theta = np.asarray(theta, dtype=np.float64)
+    b, k, g = theta[..., 0], theta[..., 1], theta[..., 2]
+    S, E, I = X[..., 0, 0], X[..., 1, 0], X[..., 2, 0]
+    return np.stack([-b * S * I, b * S * I - k * E, k * E - g * I, g * I], axis=-1)[..., None]
+
+
+@pytest.mark.parametrize("p,lay", [(3, "TILE3"), (4, "TILE4")])
+def test_four_block_user_ode_and_three_block_builtin_on_the_tile_path(ra, p, lay):
+    """n_block = 4 (four tiles of a wave = one trajectory, values exchanged by masked DPP rotations) for a user ODE with
+    dual-number Jacobian, and the built-in Lorenz63 (n_block = 3) at p = 3, against the oracle."""
+    from rodeo_amd import _lib
+    seir = ra.ode.from_source("AutoJac<Seir4>", SEIR4_SRC, 4, (("theta", 3),), _seir_host, name="seir4_p%d" % p)
+
+    def jac(X, t, theta):
+        theta = np.asarray(theta, dtype=np.float64)
+        b, k, g = theta[..., 0], theta[..., 1], theta[..., 2]
+        S, I = X[..., 0, 0], X[..., 2, 0]
+        J = np.zeros(np.broadcast_shapes(X.shape[:-2], theta.shape[:-1]) + (4, 1, X.shape[-1]))
+        J[..., 0, 0, 0] = -b * I
+        J[..., 1, 0, 0] = -k
+        J[..., 2, 0, 0] = -g
+        return J
+    o_ode = odes.ODE("seir4", 4, 1, lambda X, t, theta: _seir_host(X, t, theta), jac)
+    B, N = 5, 70
+    rng = np.random.default_rng(4)
+    theta = np.array([1.8, 0.6, 0.4]) * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(seir, 4, p)
+    x0 = init(np.array([0.9, 0.05, 0.05, 0.0]) + 0.01 * rng.standard_normal((B, 4)), 0.0, theta=theta)
+    prior = ra.ibm_init(7.0 / N, p, np.array([.1] * 4))
+    for name in ("kramer", "rodeo"):
+        g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+        plan = ra.SolvePlan(seir, W, x0, 0., 7., N, g, prior, theta=theta)
+        plan.mv(None)
+        assert plan.layout == getattr(_lib, "LAYOUT_" + lay)
+        m, v = plan.state_host()
+        mo, vo = scan.solve_mv(None, o_ode, W, x0, 0., 7., N, o, prior, theta=theta)
+        sm = np.max(np.abs(mo), axis=(0, 1, 2))
+        assert np.max(np.abs(m - mo) / sm) < 1e-8
+        assert np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))
+    if p == 3:
+        th = np.array([28., 10., 8. / 3.])
+        Wl, initl = ra.utils.first_order_pad(ra.ode.lorenz63, 3, 3)
+        xl = initl(np.array([-12., -5., 38.]) + 0.01 * rng.standard_normal((3, 3)), 0.0, theta=th)
+        pl = ra.ibm_init(1e-3, 3, np.array([5e3] * 3))
+        plan = ra.SolvePlan(ra.ode.lorenz63, Wl, xl, 0., 0.3, 300, ra.interrogate.interrogate_kramer, pl, theta=th)
+        plan.mv(None)
+        assert plan.layout == _lib.LAYOUT_TILE3
+        m, v = plan.state_host()
+        mo, vo = scan.solve_mv(None, odes.lorenz63, Wl, xl, 0., 0.3, 300, oi.interrogate_kramer, pl, theta=th)
+        assert np.max(np.abs(m[..., 0] - mo[..., 0])) < 1e-7
+        x = ra.solve_sim(9, ra.ode.lorenz63, Wl, xl, 0., 0.3, 300, ra.interrogate.interrogate_rodeo, pl, theta=th)
+        xo = scan.solve_sim(9, odes.lorenz63, Wl, xl, 0., 0.3, 300, oi.interrogate_rodeo, pl, theta=th)
+        assert np.max(np.abs(x[..., 0] - xo[..., 0])) < 1e-6
