@@ -86,7 +86,7 @@ __device__ __forceinline__ void gather_blocks(double own, double (&vals)[D]) {
         vals[1] = dpp64_banks<0x124, 0x4>(dpp64_banks<0x12C, 0x1>(own, own), own);   // g=0 <- g+1, g=2 <- g-1
         vals[2] = dpp64_banks<0x12C, 0x2>(dpp64_banks<0x128, 0x1>(own, own), own);   // g=0 <- g+2, g=1 <- g+1
     } else {
-        static_assert(D == 4, "gather_blocks: n_block in {1, 2, 3, 4}");
+        static_assert(D == 4, "gather_blocks: n_block in {1, 2, 3, 4} (more blocks go through LDS)");
         // block k's value goes to tile g by a rotation of (g - k) tiles: one masked move per distance
         vals[0] = dpp64_banks<0x12C, 0x8>(dpp64_banks<0x128, 0x4>(dpp64_banks<0x124, 0x2>(own, own), own), own);
         vals[1] = dpp64_banks<0x128, 0x8>(dpp64_banks<0x124, 0x4>(dpp64_banks<0x12C, 0x1>(own, own), own), own);
@@ -100,7 +100,13 @@ __device__ __forceinline__ double pick_block(const double (&v)[D], int blk) {
     if constexpr (D == 1) return v[0];
     else if constexpr (D == 2) return blk == 0 ? v[0] : v[1];
     else if constexpr (D == 3) return blk == 0 ? v[0] : (blk == 1 ? v[1] : v[2]);
-    else return blk < 2 ? (blk == 0 ? v[0] : v[1]) : (blk == 2 ? v[2] : v[3]);
+    else if constexpr (D == 4) return blk < 2 ? (blk == 0 ? v[0] : v[1]) : (blk == 2 ? v[2] : v[3]);
+    else {
+        double x = v[0];
+#pragma unroll
+        for (int k = 1; k < D; ++k) x = blk == k ? v[k] : x;
+        return x;
+    }
 }
 
 // ---- LDS hand-off swizzles of the backward kernels (producer lanes: one per item; consumer lanes: tile elements) ----

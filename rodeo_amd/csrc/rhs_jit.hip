@@ -124,7 +124,7 @@ bool user_tile_available(const rk_solve_cfg* c, int which) {
     if (idx < 0 || idx >= (int)g_rhs.size()) return false;
     const int nb = g_rhs[idx].n_block;
     if (c->n_block != nb || c->n_bmeas != 1 || c->kalman_type != RK_KALMAN_STANDARD) return false;
-    if (nb < 1 || nb > 4) return false;                          // the blocks of a trajectory share a wave
+    if (nb < 1 || nb > (which == 3 ? 16 : 4)) return false;      // p = 3: up to 16 blocks (4 per wave, LDS exchange); p = 4: one wave
     const JitCode& jc = jit_code_locked(c->rhs_id, which, c->interrogate, which);
     if (jc.rc && getenv("RK_JIT_VERBOSE")) fprintf(stderr, "[rk] tile kernel not available for user rhs %d (p = %d): %s\n", c->rhs_id, which, jc.error.c_str());
     return jc.rc == RK_OK;
@@ -137,8 +137,10 @@ int user_forward_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, do
     SolveArgs args = a;
     void* params[] = {&args, &tiles};
     const int tpw = c->n_block == 3 ? 3 : 4;
+    const int nw = c->n_block <= 4 ? 1 : (c->n_block + 3) / 4;     // waves per workgroup (TileWaves<D>)
+    const int grid = nw == 1 ? div_up(a.B * c->n_block, tpw) : a.B;
     LaunchTimer t(h, which == 3 ? "fwd_tile3_kernel<user>" : "fwd_tile4_kernel<user>");
-    RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B * c->n_block, tpw), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));
+    RK_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 64 * nw, 1, 1, 0, h->stream, params, nullptr));
     t.stop();
     return RK_OK;
 }

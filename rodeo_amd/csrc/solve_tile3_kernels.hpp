@@ -33,13 +33,33 @@ __device__ __forceinline__ TileCoord tile_coord(int wave, int lane, int n_tiles)
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
+// n_block <= 4: one wave per workgroup carries whole trajectories (Tpw<D> tiles).  n_block = 5..16: a workgroup of
+// ceil(D / 4) waves is ONE trajectory, wave w holds blocks 4 w .. 4 w + 3, and the evaluation points of all blocks are
+// exchanged through LDS once per step (one barrier; double-buffered so that no second one is needed).
+constexpr int TILE_MAX_BLOCKS = 16;
+
+template <int D>
+struct TileWaves {                               // waves per forward workgroup
+    static constexpr int value = D <= 4 ? 1 : (D + 3) / 4;
+};
+
 template <class RHS, int ITG>
-__global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __restrict__ tiles) {
-    constexpr int D = RHS::D, P = 3, TPW = Tpw<D>::value;
-    static_assert(D >= 1 && D <= 4, "tile path: n_block in 1..4 (the blocks of a trajectory share a wave)");
+__global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kernel(SolveArgs a, double* __restrict__ tiles) {
+    constexpr int D = RHS::D, P = 3, NW = TileWaves<D>::value, TPW = NW > 1 ? 4 : Tpw<D>::value;
+    static_assert(D >= 1 && D <= TILE_MAX_BLOCKS, "tile path: n_block in 1..16");
     static_assert(RHS::NDEP == 1, "tile path: right-hand sides that depend on X[b][0] only");
     const int n_tiles = a.B * D;
-    const TileCoord tc = tile_coord<D, TPW>(blockIdx.x, threadIdx.x, n_tiles);
+    const int wave_in_wg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    TileCoord tc;
+    if constexpr (NW == 1) {
+        tc = tile_coord<D, TPW>(blockIdx.x, lane, n_tiles);
+    } else {
+        tc.r = lane >> 4; tc.g = (lane >> 2) & 3; tc.c = lane & 3;
+        const int blk_w = wave_in_wg * 4 + tc.g;
+        tc.valid = blk_w < D;
+        tc.b = blockIdx.x; tc.blk = tc.valid ? blk_w : D - 1;       // (idle slots of the last wave repeat the last block)
+        tc.tau = tc.b * D + tc.blk;
+    }
     const int r = tc.r, c = tc.c, b = tc.b, blk = tc.blk;
     const bool in3 = r < 3 && c < 3;
 
@@ -70,7 +90,9 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
         if (r == 3) { c3 = k5 - tk[1]; c1 = k4 - tk[0]; co = -tk[2]; c0 = -tk[3]; }
         if (r == 0) { c2 = -k5; c0 = Wr - k4; }
     }
-    __shared__ double zbuf[4 * 16];                    // chkrebtii: z_0 of the next 16 steps for each of the 4 tiles
+    __shared__ double zbuf_all[NW][4 * 16];            // chkrebtii: z_0 of the next 16 steps for each of the wave's 4 tiles
+    double* const zbuf = zbuf_all[wave_in_wg];
+    __shared__ double vx[2][NW > 1 ? TILE_MAX_BLOCKS : 1];   // NW > 1: the blocks' evaluation points of this / the next step
     const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
 
     // M_0 = [0 | ode_init ; 0 1]   (solve.py:53-54)
@@ -81,7 +103,7 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
     // In the loop every lane stores through a buffer window on this wave's part of the time row (scalar base, no
     // per-lane pointer arithmetic: every VALU instruction lengthens the dependent chain); slot-less lanes are out of
     // range and dropped by the hardware.
-    const char* row = (const char*)(tiles + (size_t)blockIdx.x * TPW * TILE_DOUBLES);
+    const char* row = (const char*)(tiles + (NW == 1 ? (size_t)blockIdx.x * TPW : (size_t)blockIdx.x * D + (size_t)wave_in_wg * 4) * TILE_DOUBLES);
     const int bvoff = st ? (int)((tc.g * TILE_DOUBLES + r * 4 + c) * sizeof(double)) : (int)0x80000000;
     auto store_row = [&](double v) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, TPW * TILE_DOUBLES * 8, 0x00020000);
@@ -174,11 +196,16 @@ __global__ void __launch_bounds__(64) fwd_tile3_kernel(SolveArgs a, double* __re
             for (int bb = 0; bb < D; ++bb)
 #pragma unroll
                 for (int j = 0; j < P; ++j) X[bb][j] = 0.0;
-            {
+            if constexpr (NW == 1) {
                 double vals[D];
                 gather_blocks<D>(v_own, vals);
 #pragma unroll
                 for (int bb = 0; bb < D; ++bb) X[bb][0] = vals[bb];
+            } else {
+                if (tc.valid && r == 0 && c == 0) vx[n & 1][blk] = v_own;
+                __syncthreads();
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) X[bb][0] = vx[n & 1][bb];
             }
             double fb, J0;
             if constexpr (ITG == RK_INTERROGATE_KRAMER && rhs_has_fjac0<RHS>::value) {

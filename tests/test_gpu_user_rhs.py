@@ -170,3 +170,74 @@ def test_four_block_user_ode_and_three_block_builtin_on_the_tile_path(ra, p, lay
         x = ra.solve_sim(9, ra.ode.lorenz63, Wl, xl, 0., 0.3, 300, ra.interrogate.interrogate_rodeo, pl, theta=th)
         xo = scan.solve_sim(9, odes.lorenz63, Wl, xl, 0., 0.3, 300, oi.interrogate_rodeo, pl, theta=th)
         assert np.max(np.abs(x[..., 0] - xo[..., 0])) < 1e-6
+
+
+SIX_SRC = r"""
+// six coupled compartments (a SEIRAH-like chain with nonlinear infection terms), scalar-generic
+struct Six {
+    static constexpr int D = 6;
+    static constexpr int NTHETA = 4;
+    static constexpr int NDEP = 1;
+    template <class T, int P>
+    __device__ __forceinline__ static void rhs(const T (&X)[D][P], double t, const double (&th)[NTHETA], T (&out)[D]) {
+        const T S = X[0][0], E = X[1][0], I = X[2][0], R = X[3][0], A = X[4][0], H = X[5][0];
+        const double b = th[0], k = th[1], g = th[2], d = th[3];
+        out[0] = -b * S * (I + 0.5 * A);
+        out[1] = b * S * (I + 0.5 * A) - k * E;
+        out[2] = 0.6 * k * E - (g + d) * I;
+        out[3] = g * (I + A) + 0.2 * H + 0.0 * R;
+        out[4] = 0.4 * k * E - g * A;
+        out[5] = d * I - 0.2 * H;
+    }
+};
+"""
+
+
+def _six_host(X, t, theta):
+    th = np.asarray(theta, dtype=np.float64)
+    b, k, g, d = th[..., 0], th[..., 1], th[..., 2], th[..., 3]
+    S, E, I, R, A, H = (X[..., i, 0] for i in range(6))
+    inf = b * S * (I + 0.5 * A)
+    return np.stack([-inf, inf - k * E, 0.6 * k * E - (g + d) * I, g * (I + A) + 0.2 * H, 0.4 * k * E - g * A,
+                     d * I - 0.2 * H], axis=-1)[..., None]
+
+
+def test_six_block_user_ode_multi_wave_tile_path(ra):
+    """n_block = 6 at p = 3: two waves per trajectory, evaluation points exchanged through LDS every step."""
+    from rodeo_amd import _lib
+    six = ra.ode.from_source("AutoJac<Six>", SIX_SRC, 6, (("theta", 4),), _six_host, name="six_p3")
+
+    def jac(X, t, theta):
+        th = np.asarray(theta, dtype=np.float64)
+        b, k, g, d = th[..., 0], th[..., 1], th[..., 2], th[..., 3]
+        S, I, A = X[..., 0, 0], X[..., 2, 0], X[..., 4, 0]
+        J = np.zeros(np.broadcast_shapes(X.shape[:-2], th.shape[:-1]) + (6, 1, X.shape[-1]))
+        J[..., 0, 0, 0] = -b * (I + 0.5 * A)
+        J[..., 1, 0, 0] = -k
+        J[..., 2, 0, 0] = -(g + d)
+        J[..., 3, 0, 0] = 0.0
+        J[..., 4, 0, 0] = -g
+        J[..., 5, 0, 0] = -0.2
+        return J
+    o_ode = odes.ODE("six", 6, 1, lambda X, t, theta: _six_host(X, t, theta), jac)
+    B, N, p = 5, 60, 3
+    rng = np.random.default_rng(6)
+    theta = np.array([2.0, 0.7, 0.3, 0.1]) * np.exp(0.05 * rng.standard_normal((B, 4)))
+    W, init = ra.utils.first_order_pad(six, 6, p)
+    x0 = init(np.array([0.9, 0.04, 0.03, 0.0, 0.03, 0.0]) + 0.005 * rng.standard_normal((B, 6)), 0.0, theta=theta)
+    prior = ra.ibm_init(6.0 / N, p, np.array([.1] * 6))
+    for name in ("kramer", "schober"):
+        g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+        plan = ra.SolvePlan(six, W, x0, 0., 6., N, g, prior, theta=theta)
+        plan.mv(None)
+        assert plan.layout == _lib.LAYOUT_TILE3
+        m, v = plan.state_host()
+        mo, vo = scan.solve_mv(None, o_ode, W, x0, 0., 6., N, o, prior, theta=theta)
+        sm = np.maximum(np.max(np.abs(mo), axis=(0, 1, 2)), 1e-3)
+        assert np.max(np.abs(m - mo) / sm) < 1e-8
+        assert np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))
+    x = ra.solve_sim(4, six, W, x0, 0., 6., N, functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="standard"),
+                     prior, theta=theta)
+    xo = scan.solve_sim(4, o_ode, W, x0, 0., 6., N, functools.partial(oi.interrogate_chkrebtii, kalman_type="standard"),
+                        prior, theta=theta)
+    assert np.max(np.abs(x - xo)) < 1e-6
