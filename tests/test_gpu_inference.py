@@ -168,3 +168,44 @@ def test_fenrir_parity(ra, name):
     with pytest.raises(NotImplementedError):
         ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], y, s["obs_times"], Dw, Om,
                             kalman_type="cubature", theta=s["theta"])
+
+
+def test_config4_full_size_per_gpu(ra):
+    """
+    BASELINE.json config 4 at its per-GPU size (1024 parameter draws, FN, N=800, solve_sim + interrogate_chkrebtii,
+    41 observations, log-posterior on the device): sampled draws against the oracle with the shared Philox stream
+    (global draw index = traj_offset + b, as on rank 3 of 8), the download-and-reduce value for every draw, and
+    invariance to the batch the draw sits in.
+    """
+    from rodeo_amd.inference import gauss_obs_logpost, obs_index
+    B, N, off = 1024, 800, 3 * 1024
+    rng = np.random.default_rng(20242)
+    u0 = np.concatenate([np.log([.2, .2, 3.]), [-1., 1.], [.1, .1]])
+    upars = u0 + np.array([0.01, 0.1, 0.01, 0.01, 0.01, 0.01, 0.01]) * rng.standard_normal((B, 7))
+    theta, x0v, sigma = np.exp(upars[:, :3]), upars[:, 3:5], upars[:, 5:]
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    X0 = init(x0v, 0., theta=theta)
+    prior = ra.ibm_init(40.0 / N, 3, sigma)
+    g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="standard")
+    o = functools.partial(oi.interrogate_chkrebtii, kalman_type="standard")
+    obs_t = np.linspace(0, 40, 41)
+    ind = obs_index(0., 40., N, obs_t)
+    Y = np.array([-1., 1.]) + rng.standard_normal((41, 2))
+    sd = np.sqrt(0.005)
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, X0, 0., 40., N, g, prior, traj_offset=off, theta=theta)
+    plan.sim(20242)
+    lp = gauss_obs_logpost(plan, Y, ind, sd, upars=upars, prior_sd=10.0, n_prior=5).to_host()
+    assert lp.shape == (B,) and np.all(np.isfinite(lp))
+    x = plan.x_host()
+    assert x.shape == (B, N + 1, 2, 3)
+    ref = np.sum(norm.logpdf(Y[None], loc=x[:, ind][..., 0], scale=sd), axis=(1, 2)) + np.sum(norm.logpdf(upars[:, :5], 0., 10.), axis=1)
+    np.testing.assert_allclose(lp, ref, rtol=1e-12, atol=1e-8)
+    for b in (0, 511, 1023):
+        sl = slice(b, b + 1)
+        xo = scan.solve_sim(20242, odes.fitzhugh_nagumo, W, X0[sl], 0., 40., N, o, (prior[0], prior[1][sl]),
+                            traj_offset=off + b, theta=theta[sl])
+        assert np.max(np.abs(x[b] - xo[0])) < 1e-6
+        p1 = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, X0[sl], 0., 40., N, g, (prior[0], prior[1][sl]), traj_offset=off + b,
+                          theta=theta[sl])
+        p1.sim(20242)
+        np.testing.assert_array_equal(p1.x_host()[0], x[b])

@@ -474,3 +474,42 @@ def test_square_root_higher_order_example(ra):
     mo, Lo = scan.solve_mv(None, odes.higher_order, W, x0, 0.0, 10.0, N, oi.interrogate_kramer,
                            (Q, np.linalg.cholesky(R)), kalman_type="square-root")
     assert np.max(np.abs(m - mo)) < 1e-8
+
+
+def test_config3_full_size_properties(ra):
+    """
+    BASELINE.json config 3 at full size (Lorenz63, p=4, N=20000, B=512, kramer, solve_mv; MFMA tile4 kernels):
+    sampled trajectories against the plain-C oracle over the whole (chaotic) horizon, the same trajectory solved alone
+    (no cross-tile leakage, bit-exact), end conditions, finite symmetric variances.
+    """
+    from oracle import c_port
+    from rodeo_amd import _lib
+    B, N, p = 512, 20000, 4
+    rng = np.random.default_rng(20241)
+    theta = np.array([28., 10., 8. / 3.])
+    W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, p)
+    x0 = init(np.array([-12., -5., 38.]) + 1e-3 * rng.standard_normal((B, 3)), 0.0, theta=theta)
+    prior = ra.ibm_init(20.0 / N, p, np.array([5e7] * 3))
+    plan = ra.SolvePlan(ra.ode.lorenz63, W, x0, 0.0, 20.0, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
+    plan.mv(None)
+    assert plan.layout == _lib.LAYOUT_TILE4
+    m, v = plan.state_host()
+    assert m.shape == (B, N + 1, 3, 4) and v.shape == (B, N + 1, 3, 4, 4)
+    np.testing.assert_array_equal(m[:, 0], x0); assert np.all(v[:, 0] == 0)
+    sample = [0, 1, 170, 511]
+    mo, vo = c_port.solve_mv("lorenz63", "kramer", W, x0[sample], 0.0, 20.0, N, prior, theta=theta)
+    sm = np.max(np.abs(mo), axis=(0, 1, 2))
+    # chaotic: rounding differences grow like exp(0.9 t) -- measured 1.1e-10 of the scale up to t = 10, 6.5e-8 at
+    # t = 15, 6.7e-6 at t = 20 (the covariances do not depend on the path: 8e-10 throughout)
+    assert np.max(np.abs(m[sample][:, :N // 2] - mo[:, :N // 2]) / sm) < 1e-8
+    assert np.max(np.abs(m[sample] - mo) / sm) < 1e-3
+    sd = np.sqrt(np.max(np.abs(np.einsum("bnkii->bnki", vo)), axis=(0, 1, 2)))
+    assert np.max(np.abs(v[sample] - vo) / (sd[:, None] * sd[None, :])) < 1e-7
+    for b in (1, 511):
+        m1, v1 = ra.solve_mv(None, ra.ode.lorenz63, W, x0[b], 0.0, 20.0, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
+        np.testing.assert_array_equal(m[b], m1); np.testing.assert_array_equal(v[b], v1)
+    for lo in range(0, B, 64):                       # whole-batch checks in slabs (the full result is 4.9 GB)
+        ms, vs = m[lo:lo + 64], v[lo:lo + 64]
+        assert np.all(np.isfinite(ms)) and np.all(np.isfinite(vs))
+        assert np.max(np.abs(vs - np.swapaxes(vs, -1, -2))) <= 1e-12 * np.max(np.abs(vs))
+        assert np.max(np.abs(ms[:, :, :, 0])) < 100.0                     # on the attractor
