@@ -30,144 +30,165 @@ struct DenseArgs {
     size_t ws_stride;
 };
 
-constexpr int DT = 256;
+constexpr int DT = 512, NWAVE = DT / 64;
 
-// C (M x N, ldc) = ce * E + cab * op(A) op(B); op = transpose if TA / TB.  Row-major operands in global memory; the
-// whole workgroup cooperates.  op(B) is staged through LDS in column chunks of up to 80 (K x 80 doubles = 100 KiB at
-// K = 160), each wave takes 16-row blocks of C and accumulates a block row of the chunk (up to five 16 x 16 tiles) with
-// v_mfma_f64_16x16x4_f64: per 4-deep k step ONE 8-byte global load per lane (the A fragment, prefetched four steps
-// ahead) feeds five MFMAs whose B fragments come from LDS.  So op(B) is read from memory once and A once per chunk
-// (twice at N = 160) -- the first version (32 x 32 tiles straight from memory, every operand re-read five times) was
-// bound by the 1 MB/trajectory working set streaming from HBM: 330k cycles per 160^3 product against 64k of MFMA time.
+// Optional phase timing (compile with -DRK_DENSE_STAMPS): cycles per phase, summed over the steps of workgroup 0,
+// in the spare doubles before the block-diagonal flag at the end of trajectory 0's workspace.
+#ifdef RK_DENSE_STAMPS
+#define RK_STAMP_DECL(ws_end) double* const stamps_ = (ws_end); long long stamp_t_ = __builtin_amdgcn_s_memtime()
+#define RK_STAMP(k) do { __syncthreads(); if (stamps_ && blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); stamps_[-2 - (k)] += (double)(t_ - stamp_t_); stamp_t_ = t_; } } while (0)
+#define RK_STAMP_RESET() stamp_t_ = __builtin_amdgcn_s_memtime()
+#define RK_STAMP_ZERO() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 12; ++k_) stamps_[-2 - k_] = 0.0; __syncthreads(); } while (0)
+#else
+#define RK_STAMP_DECL(ws_end)
+#define RK_STAMP(k)
+#define RK_STAMP_RESET()
+#define RK_STAMP_ZERO()
+#endif
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Arguments of a real (non-inlined) device function arrive in VGPRs and everything derived from them counts as
+// divergent (vector compares, exec-mask branches, per-lane addresses).  These make the workgroup-uniform ones scalar again.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <class T>
+__device__ __forceinline__ T* uni(T* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi_ << 32) | lo_);
+}
+
+constexpr int LDS_DOUBLES = 16384;               // 128 KiB: GEMM staging / LU panel + U strip (one workgroup per CU)
+// The workgroup's LDS, at file scope so that the real (non-inlined) device functions below address it as LDS: through
+// a pointer argument they would see a generic pointer and emit flat loads.
+__shared__ __attribute__((aligned(16))) double g_lds[LDS_DOUBLES];
+constexpr int LU_NB = 16, LU_MAXN = 320, LU_LD = LU_NB + 1;
+constexpr int BD_MAX = 8, BD_MAXP = 320;
+__shared__ int g_ppiv[LU_NB], g_cur[LU_MAXN], g_mlist[2 * LU_NB], g_mcount;
+__shared__ double g_rdiag[LU_NB];
+__shared__ double g_qd[BD_MAXP * BD_MAX];         // diagonal blocks of a block-diagonal Q
+
+// ---------------------------------------------------------------------------------------------------------------
+// C (M x N, ldc) = ce * E + cab * op(A) op(B); row-major operands in global memory, the whole workgroup cooperates.
+// v_mfma_f64_16x16x4_f64 with BOTH operands staged through LDS in k-chunks of 32 (As[k][i], Bs[k][j], row stride 177
+// doubles: the fragment reads and the transposing stores are both at most 2-way on the banks), so a transposed operand
+// only changes how its chunk is staged and there is ONE copy of the inner loop: the kernels issue their products
+// from a descriptor loop (GemmOp), not from inlined call sites -- the first version of this file inlined a templated
+// GEMM at every call site (22 000 instructions per kernel, several times the instruction cache) and ran one wave per
+// SIMD, so nothing overlapped its MFMAs.  The output is processed in 160 x 160 macro-blocks of 16 x 16 tiles; wave w
+// owns tiles w, w + 16, ... (at most 7) and keeps their accumulators in registers across the k-chunks.
 // E may alias C (each element is read and written by the same lane).
 // Fragment layout (profiles/r01_probe10_mfma_f64_16x16x4.log): A lane = 16 k + i, B lane = 16 k + j,
-// D[i][j] in lane 16 (i % 4) + j, register i / 4; one MFMA = 64 cycles = the SIMD's fp64 peak, also with a single
-// accumulator chain.
-typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int GEMM_LDS_DOUBLES = 12800;          // 100 KiB, shared with the LU panel
-constexpr int GEMM_MAX_NC = 80;
+// D[i][j] in lane 16 (i % 4) + j, register i / 4; one MFMA = 64 cycles.
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmOp {
+    double* C; int ldc;
+    const double* A; int lda;
+    const double* B; int ldb;
+    int M, N, K;
+    const double* E; int lde;
+    double ce, cab;
+    bool ta, tb;
+};
+constexpr int G_KC = 32, G_SP = 177, G_MB = 160, G_TPW = ((G_MB / 16) * (G_MB / 16) + NWAVE - 1) / NWAVE;
+static_assert(2 * G_KC * G_SP <= LDS_DOUBLES, "GEMM staging exceeds the LDS buffer");
+static_assert((G_MB / 16) * (G_MB / 16) <= G_TPW * NWAVE, "tiles per wave");
 
-// One wave's 16-row block of C against the staged chunk (NT tiles of 16 columns): the k loop.  A fragments are loaded
-// PF steps ahead with clamped indices and NO select behind the load (a select would make hipcc wait for the load at
-// once): rows past M are never stored, and columns past K meet the zero rows of the staged op(B).
-template <bool TA, int NT>
-__device__ __forceinline__ void gemm_row_block(const double* lds, int NCP, int Kp, double* C, int ldc, const double* A, int lda,
-                                               int M, int N, int K, const double* E, int lde, double ce, double cab,
-                                               int ib, int jc) {
-    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
-    const int ci = min(ib + lo, M - 1);
-    const double* arow = TA ? A + ci : A + (size_t)ci * lda;
-    const size_t astep = TA ? (size_t)lda : 1;                    // address step per k
-    auto ldA = [&](int k) -> double { return arow[(size_t)min(k, K - 1) * astep]; };
-    constexpr int PF = 4;
-    double fa[PF];
+// dst[k][j] = src[k * ld + j] for k < kn, j < jn; zero elsewhere in the 32 x 160 chunk  (source rows -> LDS rows)
+__device__ __forceinline__ void stage_rows(double* dst, const double* src, int ld, int kn, int jn) {
+    constexpr int IT = G_KC * G_MB / DT;
+    static_assert(IT * DT == G_KC * G_MB && IT % 5 == 0, "chunk size / workgroup size");
+    for (int q0 = 0; q0 < IT; q0 += 5) {
+        double v[5];
 #pragma unroll
-    for (int q = 0; q < PF; ++q) fa[q] = ldA(4 * q + hi);
-    d4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = d4{0, 0, 0, 0};
-    const double* brow = lds + hi * NCP + lo;
-    double bc[NT];                                                // B fragments, read from LDS one k step ahead
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bc[t] = brow[16 * t];
-    for (int k0 = 0; k0 < Kp; k0 += 4 * PF) {
-#pragma unroll
-        for (int q = 0; q < PF; ++q) {
-            const int kq = k0 + 4 * q;
-            if (kq < Kp) {
-                const double a = fa[q];
-                fa[q] = ldA(kq + 4 * PF + hi);
-                double bn[NT];
-                const int kn = min(kq + 4, Kp - 4);                 // (the last step re-reads its own rows)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bn[t] = brow[kn * NCP + 16 * t];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bc[t], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bc[t] = bn[t];
-            }
+        for (int q = 0; q < 5; ++q) {
+            const int e = threadIdx.x + (q0 + q) * DT, k = e / G_MB, j = e - k * G_MB;
+            v[q] = (k < kn && j < jn) ? src[k * ld + j] : 0.0;
         }
-    }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int ii = ib + 4 * v + hi, j = jc + 16 * t + lo;
-            if (ii < M && j < N) {
-                double x = cab * acc[t][v];
-                if (E) x = fma(ce, E[(size_t)ii * lde + j], x);
-                C[(size_t)ii * ldc + j] = x;
-            }
+        for (int q = 0; q < 5; ++q) {
+            const int e = threadIdx.x + (q0 + q) * DT, k = e / G_MB, j = e - k * G_MB;
+            dst[k * G_SP + j] = v[q];
         }
     }
 }
-
-template <bool TA, bool TB>
-__device__ __forceinline__ void wg_gemm(double* lds, double* C, int ldc, const double* A, int lda, const double* B, int ldb,
-                                        int M, int N, int K, const double* E, int lde, double ce, double cab) {
-    const int wave = threadIdx.x >> 6, n_waves = DT / 64;
-    const int Kp = (K + 3) & ~3;
-    int NC = min(GEMM_MAX_NC, GEMM_LDS_DOUBLES / Kp / 16 * 16);  // chunk width (multiple of 16; K <= 768: dense_check)
-    if (NC > ((N + 15) & ~15)) NC = (N + 15) & ~15;
-    if (NC % 32 == 0 && Kp * (NC + 16) > GEMM_LDS_DOUBLES) NC -= 16;
-    const int NCP = (NC % 32 == 0) ? NC + 16 : NC;               // row stride = 16 (mod 32) doubles: the fragment's four k rows
-                                                                 // fall into alternating halves of the 64 banks
-    for (int jc = 0; jc < N; jc += NC) {
-        const int nc = min(NC, N - jc), n_tile = (nc + 15) >> 4;
-        // stage op(B)[0:Kp, jc:jc + 16 n_tile) (zero outside K x nc): threads as a 16 x 16 grid, 128 contiguous bytes per
-        // row of 16 threads, up to 2 x 5 independent loads in flight per thread
-        {
-            const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-            if (TB) {
-                for (int k1 = 0; k1 < Kp; k1 += 32) {
-                    double v[2][GEMM_MAX_NC / 16];
+// dst[k][i] = src[i * ld + k]  (source rows -> LDS columns): 8 lanes cover 32 consecutive k of one source row
+__device__ __forceinline__ void stage_cols(double* dst, const double* src, int ld, int kn, int in) {
+    for (int e = threadIdx.x; e < G_MB * 8; e += DT) {
+        const int kg = e & 7, i = e >> 3;
+        double v[4];
 #pragma unroll
-                    for (int r = 0; r < 2; ++r)
+        for (int u = 0; u < 4; ++u) v[u] = (4 * kg + u < kn && i < in) ? src[i * ld + 4 * kg + u] : 0.0;
 #pragma unroll
-                        for (int t = 0; t < GEMM_MAX_NC / 16; ++t) {
-                            const int k = k1 + 16 * r + tx, j = 16 * t + ty;
-                            v[r][t] = (t < n_tile && k < K && j < nc) ? B[(size_t)(jc + j) * ldb + k] : 0.0;
-                        }
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int t = 0; t < GEMM_MAX_NC / 16; ++t) {
-                            const int k = k1 + 16 * r + tx, j = 16 * t + ty;
-                            if (t < n_tile && k < Kp) lds[k * NCP + j] = v[r][t];
-                        }
-                }
-            } else {
-                for (int k1 = 0; k1 < Kp; k1 += 32) {
-                    double v[2][GEMM_MAX_NC / 16];
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int t = 0; t < GEMM_MAX_NC / 16; ++t) {
-                            const int k = k1 + 16 * r + ty, j = 16 * t + tx;
-                            v[r][t] = (t < n_tile && k < K && j < nc) ? B[(size_t)k * ldb + jc + j] : 0.0;
-                        }
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int t = 0; t < GEMM_MAX_NC / 16; ++t) {
-                            const int k = k1 + 16 * r + ty, j = 16 * t + tx;
-                            if (t < n_tile && k < Kp) lds[k * NCP + j] = v[r][t];
-                        }
-                }
-            }
-        }
-        __syncthreads();
-        for (int ib = wave * 16; ib < M; ib += n_waves * 16) {
-            switch (n_tile) {           // compile-time tile count: no branches inside the k loop
-                case 1: gemm_row_block<TA, 1>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
-                case 2: gemm_row_block<TA, 2>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
-                case 3: gemm_row_block<TA, 3>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
-                case 4: gemm_row_block<TA, 4>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
-                default: gemm_row_block<TA, 5>(lds, NCP, Kp, C, ldc, A, lda, M, N, K, E, lde, ce, cab, ib, jc); break;
-            }
-        }
-        __syncthreads();
+        for (int u = 0; u < 4; ++u) dst[(4 * kg + u) * G_SP + i] = v[u];
     }
+}
+
+__device__ __noinline__ void wg_gemm(const GemmOp& g_) {
+    double* const lds = g_lds;
+    const GemmOp& gr = *uni(&g_);
+    GemmOp g;
+    g.C = uni(gr.C); g.ldc = uni(gr.ldc); g.A = uni(gr.A); g.lda = uni(gr.lda); g.B = uni(gr.B); g.ldb = uni(gr.ldb);
+    g.M = uni(gr.M); g.N = uni(gr.N); g.K = uni(gr.K); g.E = uni(gr.E); g.lde = uni(gr.lde);
+    g.ce = uni(gr.ce); g.cab = uni(gr.cab); g.ta = uni((int)gr.ta) != 0; g.tb = uni((int)gr.tb) != 0;
+    double* const As = lds;
+    double* const Bs = lds + G_KC * G_SP;
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    const int wave = uni((int)(threadIdx.x >> 6));                  // tile bookkeeping stays scalar
+    const int frag = hi * G_SP + lo;
+    for (int i0 = 0; i0 < g.M; i0 += G_MB)
+        for (int j0 = 0; j0 < g.N; j0 += G_MB) {
+            const int mb = min(G_MB, g.M - i0), nbk = min(G_MB, g.N - j0);
+            const int nt = (nbk + 15) >> 4, T = ((mb + 15) >> 4) * nt;
+            d4 acc[G_TPW];
+#pragma unroll
+            for (int q = 0; q < G_TPW; ++q) acc[q] = d4{0, 0, 0, 0};
+            for (int k0 = 0; k0 < g.K; k0 += G_KC) {
+                const int kn = min(G_KC, g.K - k0);
+                __syncthreads();                                    // the previous chunk has been consumed
+                if (g.ta) stage_rows(As, g.A + (size_t)k0 * g.lda + i0, g.lda, kn, mb);      // A is K x M
+                else      stage_cols(As, g.A + (size_t)i0 * g.lda + k0, g.lda, kn, mb);      // A is M x K
+                if (g.tb) stage_cols(Bs, g.B + (size_t)j0 * g.ldb + k0, g.ldb, kn, nbk);     // B is N x K
+                else      stage_rows(Bs, g.B + (size_t)k0 * g.ldb + j0, g.ldb, kn, nbk);     // B is K x N
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < G_TPW; ++q) {
+                    const int e = wave + NWAVE * q;
+                    if (e < T) {
+                        const int ti = e / nt, tj = e - ti * nt;
+                        const double* ap = As + frag + 16 * ti;
+                        const double* bp = Bs + frag + 16 * tj;
+#pragma unroll
+                        for (int kq = 0; kq < G_KC / 4; ++kq)
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kq * G_SP], bp[4 * kq * G_SP], acc[q], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < G_TPW; ++q) {
+                const int e = wave + NWAVE * q;
+                if (e < T) {
+                    const int ti = e / nt, tj = e - ti * nt;
+                    const int j = j0 + 16 * tj + lo;
+                    double ev[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int ii = i0 + 16 * ti + 4 * v + hi;
+                        ev[v] = (g.E && ii < g.M && j < g.N) ? g.E[ii * g.lde + j] : 0.0;
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int ii = i0 + 16 * ti + 4 * v + hi;
+                        if (ii < g.M && j < g.N) g.C[ii * g.ldc + j] = fma(g.ce, ev[v], g.cab * acc[q][v]);
+                    }
+                }
+            }
+        }
+    __syncthreads();
 }
 
 // y (M) = ce * e + cab * op(A) x ; A (M x K) or, if TA, A is (K x M) and op(A) = A^T
@@ -186,9 +207,9 @@ __device__ __forceinline__ void wg_gemv(double* y, const double* A, int lda, con
 
 // In-place LU with partial pivoting of A (n x n, lda) -- first maximum of |a_ik| like LAPACK getrf -- then
 // X = A^{-1} Bm for the nr right-hand-side columns of Bm (n x nr, ldb), overwritten.  piv: n ints in global memory.
-__device__ __noinline__ void wg_lu_solve_unblocked(double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
-    __shared__ double red_v[DT];
-    __shared__ int red_i[DT];
+__device__ __noinline__ void wg_lu_solve_unblocked(double* lds, double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
+    double* const red_v = lds;                             // DT doubles
+    int* const red_i = (int*)(lds + DT);                   // DT ints
     for (int k = 0; k < n; ++k) {
         // pivot search
         double best = -1.0;
@@ -255,133 +276,292 @@ __device__ __noinline__ void wg_lu_solve_unblocked(double* A, int lda, double* B
     __syncthreads();
 }
 
-// Blocked version of the above (right-looking, panels of 16 columns factored in LDS, trailing updates and the
-// right-hand sides' block updates by wg_gemm on the MFMA): same pivots (first maximum of |a_ik|, LAPACK getrf) and the
-// same L, U up to the order of summation.  The triangular solves with the 16 x 16 diagonal blocks run one thread per
-// column; divisions by the pivots are multiplications with their reciprocals (as getf2 scales its columns).
-constexpr int LU_NB = 16, LU_MAXN = 320, LU_LD = LU_NB + 1;
+// ---------------------------------------------------------------------------------------------------------------
+// Blocked LU solve (right-looking, panels of 16 columns): same pivots (first maximum of |a_ik|, LAPACK getrf) and the
+// same L, U up to the order of summation; divisions by the pivots are multiplications with their reciprocals (as
+// getf2 scales its columns).  Per panel:
+//   1. the panel (rows k0.., 16 columns) is copied to LDS and factored by WAVE 0 ALONE, wave-synchronously (no
+//      workgroup barrier inside the 16 columns; maximum and first index through DPP row reductions + readlane);
+//   2. the net row permutation of the panel's 16 interchanges is applied to the columns right of the panel and to the
+//      right-hand sides in one parallel gather / scatter (the columns left of it hold L, which is never read again
+//      because the right-hand sides are eliminated on the fly);
+//   3. U12 = L11^{-1} A12 and B1 = L11^{-1} B1, one thread per column, written to memory and to an LDS strip;
+//   4. the rank-16 update of the trailing matrix AND of the right-hand sides: 16 x 16 tiles, A fragments from the LDS
+//      panel, B fragments from the LDS strip, four MFMAs per tile straight onto the loaded C tile.
+// Back substitution: per 16-row block from the bottom, a thread-per-column solve with U11 and the same rank-16 update
+// of the rows above.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {        // LDS traffic between the lanes of ONE wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int CTRL>
+__device__ __forceinline__ double dense_dpp64(double x) {
+    int lo_ = __double2loint(x), hi_ = __double2hiint(x);
+    lo_ = __builtin_amdgcn_update_dpp(lo_, lo_, CTRL, 0xF, 0xF, false);
+    hi_ = __builtin_amdgcn_update_dpp(hi_, hi_, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi_, lo_);
+}
+// maximum over the wave, in every lane (values >= 0 or -1)
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dense_dpp64<0xB1>(v));                    // quad_perm [1,0,3,2]
+    v = fmax(v, dense_dpp64<0x4E>(v));                    // quad_perm [2,3,0,1]
+    v = fmax(v, dense_dpp64<0x141>(v));                   // row_half_mirror
+    v = fmax(v, dense_dpp64<0x140>(v));                   // row_mirror
+    double m = -1.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lo_ = __builtin_amdgcn_readlane(__double2loint(v), 16 * r), hi_ = __builtin_amdgcn_readlane(__double2hiint(v), 16 * r);
+        m = fmax(m, __hiloint2double(hi_, lo_));
+    }
+    return m;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = min(m, __builtin_amdgcn_readlane(v, 16 * r));
+    return m;
+}
 
-__device__ __forceinline__ void wg_lu_solve(double* lds, double* A, int lda, double* Bm, int ldb, int n, int nr, int* piv) {
-    if (n > LU_MAXN) { wg_lu_solve_unblocked(A, lda, Bm, ldb, n, nr, piv); return; }
-    double* const panel = lds;                         // rows k0.. of the current panel, row stride 17 (bank spread); the
-                                                       // buffer is free again whenever a wg_gemm is called
-    __shared__ double red_v[DT / 64];
-    __shared__ int red_i[DT / 64];
-    __shared__ int ppiv[LU_NB];
-    __shared__ double rdiag[LU_NB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k0 = 0; k0 < n; k0 += LU_NB) {
-        const int nb = min(LU_NB, n - k0), rows = n - k0;
-        for (int e = tid; e < rows * nb; e += DT) panel[(e / nb) * LU_LD + e % nb] = A[(size_t)(k0 + e / nb) * lda + k0 + e % nb];
-        __syncthreads();
-        for (int j = 0; j < nb; ++j) {
-            // pivot search in panel column j, rows j..rows-1: first maximum
-            double best = -1.0;
-            int bi = j;
-            for (int r = j + tid; r < rows; r += DT) {
+// wave 0: factor the LDS panel (rows x nb, row stride LU_LD) in place; ppiv[j] = pivot row of column j (panel-relative);
+// cur[r] = the original (panel-relative) row that ends up in position r.
+__device__ __noinline__ void lu_panel_wave(int rows_, int nb_) {
+    double* const panel = g_lds;
+    int* const ppiv = g_ppiv;
+    int* const cur = g_cur;
+    const int rows = uni(rows_), nb = uni(nb_);
+    const int l = threadIdx.x;                             // lane of wave 0
+    for (int j = 0; j < nb; ++j) {
+        double best = -1.0;
+        int bi = 0x7fffffff;
+        for (int r = l; r < rows; r += 64)
+            if (r >= j) {
                 const double v = fabs(panel[r * LU_LD + j]);
-                if (v > best) { best = v; bi = r; }
+                if (v > best) { best = v; bi = r; }         // ascending rows per lane: its first maximum
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double v2 = __shfl_xor(best, off);
-                const int i2 = __shfl_xor(bi, off);
-                if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
-            }
-            if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
-            __syncthreads();
-            best = red_v[0]; bi = red_i[0];
-#pragma unroll
-            for (int w = 1; w < DT / 64; ++w) {
-                const double v2 = red_v[w];
-                const int i2 = red_i[w];
-                if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
-            }
-            const int pj = bi;
-            if (tid < nb && pj != j) {
-                const double t = panel[j * LU_LD + tid];
-                panel[j * LU_LD + tid] = panel[pj * LU_LD + tid];
-                panel[pj * LU_LD + tid] = t;
-            }
-            if (tid == 0) ppiv[j] = k0 + pj;
-            __syncthreads();
-            const double rinv = 1.0 / panel[j * LU_LD + j];
-            for (int r = j + 1 + tid; r < rows; r += DT) {
-                const double l = panel[r * LU_LD + j] * rinv;
-                panel[r * LU_LD + j] = l;
-                for (int c = j + 1; c < nb; ++c) panel[r * LU_LD + c] = fma(-l, panel[j * LU_LD + c], panel[r * LU_LD + c]);
-            }
-            __syncthreads();
+        const double m = wave_max_f64(best);
+        int pj = wave_min_i32(best == m ? bi : 0x7fffffff);
+        if (pj == 0x7fffffff) pj = j;                       // (all NaN: keep the row, like an unlucky getrf)
+        if (l == 0) {
+            ppiv[j] = pj;
+            const int t = cur[j]; cur[j] = cur[pj]; cur[pj] = t;
         }
-        // panel back to A; pivots; row interchanges on the other columns of A and on the right-hand sides
-        for (int e = tid; e < rows * nb; e += DT) A[(size_t)(k0 + e / nb) * lda + k0 + e % nb] = panel[(e / nb) * LU_LD + e % nb];
-        if (tid < nb) piv[k0 + tid] = ppiv[tid];
-        const int n_other = n - nb;
-        for (int cc = tid; cc < n_other + nr; cc += DT) {
-            double* col;
-            int ld;
-            if (cc < n_other) { col = A + (cc < k0 ? cc : cc + nb); ld = lda; } else { col = Bm + (cc - n_other); ld = ldb; }
-            for (int j = 0; j < nb; ++j) {
-                const int pk = ppiv[j];
-                if (pk != k0 + j) {
-                    const double t = col[(size_t)(k0 + j) * ld];
-                    col[(size_t)(k0 + j) * ld] = col[(size_t)pk * ld];
-                    col[(size_t)pk * ld] = t;
-                }
+        if (l < nb && pj != j) {
+            const double t = panel[j * LU_LD + l];
+            panel[j * LU_LD + l] = panel[pj * LU_LD + l];
+            panel[pj * LU_LD + l] = t;
+        }
+        wave_lds_sync();
+        double prow[LU_NB];
+#pragma unroll
+        for (int c = 0; c < LU_NB; ++c) prow[c] = panel[j * LU_LD + c];
+        const double rinv = 1.0 / panel[j * LU_LD + j];
+        for (int r = l; r < rows; r += 64)
+            if (r > j) {
+                const double lm = panel[r * LU_LD + j] * rinv;
+                panel[r * LU_LD + j] = lm;
+#pragma unroll
+                for (int c = 1; c < LU_NB; ++c)
+                    if (c > j && c < nb) panel[r * LU_LD + c] = fma(-lm, prow[c], panel[r * LU_LD + c]);
+            }
+        wave_lds_sync();
+    }
+}
+
+// rank-16 update  C <- C - L U  for the tiles (rb, ct): rows r0 + 16 rb.., a strip of column tiles; L rows from the LDS
+// panel `lp` (row stride LU_LD, row index rb * 16 + i, columns < nb), U from the LDS strip `us` (row stride usp).
+// Column tiles ct < ctA address C1 (ld1, n1 valid columns), the others C2 (ld2, n2 valid columns) at strip offset offB.
+__device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int us_off, int usp_, int rt_,
+                                            double* C1_, int ld1_, int n1_, int ctA_, double* C2_, int ld2_, int n2_, int ctB_,
+                                            int offB_, int mrows_) {
+    const double* const lp = g_lds + uni(lp_off);
+    const double* const us = g_lds + uni(us_off);
+    const int lrows = uni(lrows_), nb = uni(nb_), usp = uni(usp_), rt = uni(rt_), ld1 = uni(ld1_), n1 = uni(n1_), ctA = uni(ctA_);
+    const int ld2 = uni(ld2_), n2 = uni(n2_), ctB = uni(ctB_), offB = uni(offB_), mrows = uni(mrows_);
+    double* const C1 = uni(C1_);
+    double* const C2 = uni(C2_);
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
+    const int nct = ctA + ctB, tiles = rt * nct;
+    for (int e = wave; e < tiles; e += NWAVE) {
+        const int rb = e / nct, ct = e - rb * nct;
+        const bool inA = ct < ctA;
+        double* const Cm = inA ? C1 : C2;
+        const int ld = inA ? ld1 : ld2, ncol = inA ? n1 : n2;
+        const int cj = (inA ? ct : ct - ctA) * 16 + lo, sj = (inA ? ct * 16 : offB + (ct - ctA) * 16) + lo;
+        const bool cok = cj < ncol;
+        d4 acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ii = rb * 16 + 4 * v + hi;
+            acc[v] = (cok && ii < mrows) ? Cm[ii * ld + cj] : 0.0;
+        }
+        const int li = min(rb * 16 + lo, lrows - 1);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int k = 4 * kq + hi;
+            const double a = k < nb ? -lp[li * LU_LD + k] : 0.0;
+            const double b = us[k * usp + sj];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ii = rb * 16 + 4 * v + hi;
+            if (cok && ii < mrows) Cm[ii * ld + cj] = acc[v];
+        }
+    }
+}
+
+// Net row permutation of one panel applied to `ncols` columns of M (row stride ld, rows relative to k0): one thread
+// per column loads the (at most 32) moved rows of its column and stores them to their new places -- no barrier, no
+// thread touches another thread's column.  Row bases are uniform (scalar), the column is the per-thread offset.
+__device__ __forceinline__ void lu_swap_cols(double* M, int ld, int ncols, int nm) {
+    for (int cc = threadIdx.x; cc < ncols; cc += DT) {
+        double tmp[2 * LU_NB];
+#pragma unroll
+        for (int li = 0; li < 2 * LU_NB; ++li)
+            if (li < nm) tmp[li] = (M + uni(g_cur[g_mlist[li]]) * ld)[cc];
+#pragma unroll
+        for (int li = 0; li < 2 * LU_NB; ++li)
+            if (li < nm) (M + uni(g_mlist[li]) * ld)[cc] = tmp[li];
+    }
+}
+
+// X = L11^{-1} M for the 16-row block M (row stride ld, `ncols` columns; unit lower triangle from the LDS panel), one
+// thread per column; results to memory and to the LDS strip at column offset `soff` (zero in the padding columns up
+// to `npad` and in rows >= nb)
+__device__ __forceinline__ void lu_trsm_lower(double* M, int ld, int ncols, int npad, int nb, double* us, int usp, int soff) {
+    const double* const panel = g_lds;
+    for (int c = threadIdx.x; c < npad; c += DT) {
+        asm volatile("" ::: "memory");
+        const bool ok = c < ncols;
+        double x[LU_NB];
+#pragma unroll
+        for (int j = 0; j < LU_NB; ++j) x[j] = (ok && j < nb) ? (M + j * ld)[c] : 0.0;
+#pragma unroll
+        for (int j = 1; j < LU_NB; ++j) {
+            int pj = j * LU_LD;
+            asm("" : "+v"(pj) : "v"(x[j - 1]));          // row j's panel reads wait for x[j-1]: hipcc otherwise issues all
+                                                         // 120 reads up front and spills them
+            double sacc = x[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i)
+                if (j < nb) sacc = fma(-panel[pj + i], x[i], sacc);
+            x[j] = j < nb ? sacc : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < LU_NB; ++j) {
+            if (ok && j < nb) (M + j * ld)[c] = x[j];
+            us[j * usp + soff + c] = x[j];
+        }
+    }
+}
+
+// X1 = U11^{-1} B1 for one 16-row block of the back substitution (U11 in the LDS panel buffer at rows k0..), one
+// thread per right-hand-side column; results to memory and to the LDS strip
+__device__ __forceinline__ void lu_trsm_upper(double* M, int ld, int k0, int nb, int nr, int nbp, double* us, int usp) {
+    const double* const panel = g_lds;
+    for (int c = threadIdx.x; c < nbp; c += DT) {
+        asm volatile("" ::: "memory");
+        double x[LU_NB];
+#pragma unroll
+        for (int j = 0; j < LU_NB; ++j) x[j] = (c < nr && j < nb) ? (M + j * ld)[c] : 0.0;
+#pragma unroll
+        for (int j = LU_NB - 1; j >= 0; --j) {
+            int pj = (k0 + j) * LU_LD;
+            if (j < LU_NB - 1) asm("" : "+v"(pj) : "v"(x[j + 1]));
+            double sacc = x[j];
+#pragma unroll
+            for (int i = j + 1; i < LU_NB; ++i)
+                if (i < nb) sacc = fma(-panel[pj + i], x[i], sacc);
+            x[j] = j < nb ? sacc * g_rdiag[j] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < LU_NB; ++j) {
+            if (c < nr && j < nb) (M + j * ld)[c] = x[j];
+            us[j * usp + c] = x[j];
+        }
+    }
+}
+
+__device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int ldb_, int n_, int nr_, int* piv_,
+                                         double* ws_end_ = nullptr) {
+    double* const lds = g_lds;
+    double* const A = uni(A_);
+    double* const Bm = uni(Bm_);
+    int* const piv = uni(piv_);
+    double* const ws_end = uni(ws_end_);
+    const int lda = uni(lda_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
+    RK_STAMP_DECL(ws_end);
+    const int nrp = (n + 15) & ~15, nbp = (nr + 15) & ~15;      // strip: [0, nrt) trailing columns, [nrt, nrt + nbp) right-hand sides
+    const int usp = (nrp + nbp + 16) | 1;                       // odd row stride
+    if (n > LU_MAXN || n * LU_LD + LU_NB * usp > LDS_DOUBLES) { wg_lu_solve_unblocked(lds, A, lda, Bm, ldb, n, nr, piv); return; }
+    double* const panel = lds;
+    const int us_off = n * LU_LD;
+    const int tid = threadIdx.x;
+    for (int k0 = 0; k0 < n; k0 += LU_NB) {
+        const int nb = min(LU_NB, n - k0), rows = n - k0, n_right = n - k0 - nb;
+        for (int e = tid; e < rows * LU_NB; e += DT) {
+            const int r = e >> 4, c = e & 15;
+            if (c < nb) panel[r * LU_LD + c] = A[(k0 + r) * lda + k0 + c];
+        }
+        for (int r = tid; r < rows; r += DT) g_cur[r] = r;
+        if (tid == 0) g_mcount = 0;
+        __syncthreads();
+        if (tid < 64) lu_panel_wave(rows, nb);
+        __syncthreads();
+        RK_STAMP(1);
+        // the diagonal block back to A (its upper triangle is U11, needed by the back substitution); pivots
+        if (tid < nb * LU_NB) {
+            const int r = tid >> 4, c = tid & 15;
+            if (c < nb) A[(k0 + r) * lda + k0 + c] = panel[r * LU_LD + c];
+        }
+        if (tid < nb) piv[k0 + tid] = k0 + g_ppiv[tid];
+        for (int r = tid; r < rows; r += DT)                          // rows whose content changed
+            if (g_cur[r] != r) g_mlist[atomicAdd(&g_mcount, 1)] = r;
+        __syncthreads();
+        {
+            const int nm = g_mcount;
+            if (nm > 0) {
+                lu_swap_cols(A + (size_t)k0 * lda + k0 + nb, lda, n_right, nm);
+                lu_swap_cols(Bm + (size_t)k0 * ldb, ldb, nr, nm);
             }
         }
         __syncthreads();
-        // U12 = L11^{-1} A12 and B1 = L11^{-1} B1 (unit lower triangle from the panel), one thread per column
-        const int n_right = n - k0 - nb;
-        for (int cc = tid; cc < n_right + nr; cc += DT) {
-            double* col;
-            int ld;
-            if (cc < n_right) { col = A + k0 + nb + cc; ld = lda; } else { col = Bm + (cc - n_right); ld = ldb; }
-            double x[LU_NB];                               // constant trip counts: x stays in registers
-#pragma unroll
-            for (int j = 0; j < LU_NB; ++j) {
-                double sacc = j < nb ? col[(size_t)(k0 + j) * ld] : 0.0;
-#pragma unroll
-                for (int i = 0; i < j; ++i) sacc = fma(-panel[j * LU_LD + i], x[i], sacc);
-                x[j] = sacc;
-            }
-#pragma unroll
-            for (int j = 0; j < LU_NB; ++j)
-                if (j < nb) col[(size_t)(k0 + j) * ld] = x[j];
-        }
+        RK_STAMP(2);
+        const int nrt = (n_right + 15) & ~15;                         // trailing columns padded to whole tiles
+        lu_trsm_lower(A + (size_t)k0 * lda + k0 + nb, lda, n_right, nrt, nb, lds + us_off, usp, 0);
+        lu_trsm_lower(Bm + (size_t)k0 * ldb, ldb, nr, nbp, nb, lds + us_off, usp, nrt);
         __syncthreads();
-        if (n_right > 0) {
-            double* L21 = A + (size_t)(k0 + nb) * lda + k0;
-            double* A22 = A + (size_t)(k0 + nb) * lda + k0 + nb;
-            wg_gemm<false, false>(lds, A22, lda, L21, lda, A + (size_t)k0 * lda + k0 + nb, lda, n_right, n_right, nb, A22, lda, 1.0, -1.0);
-            double* B2 = Bm + (size_t)(k0 + nb) * ldb;
-            wg_gemm<false, false>(lds, B2, ldb, L21, lda, Bm + (size_t)k0 * ldb, ldb, n_right, nr, nb, B2, ldb, 1.0, -1.0);
-        }
+        RK_STAMP(3);
+        if (n_right > 0)
+            lu_rank_update(nb * LU_LD, n_right, nb, us_off, usp, (n_right + 15) >> 4,
+                           A + (size_t)(k0 + nb) * lda + k0 + nb, lda, n_right, nrt >> 4,
+                           Bm + (size_t)(k0 + nb) * ldb, ldb, nr, nbp >> 4, nrt, n_right);
+        __syncthreads();
+        RK_STAMP(4);
     }
     // back substitution with U, block rows from the bottom
     for (int k0 = ((n - 1) / LU_NB) * LU_NB; k0 >= 0; k0 -= LU_NB) {
         const int nb = min(LU_NB, n - k0);
-        for (int e = tid; e < nb * nb; e += DT) panel[(e / nb) * LU_LD + e % nb] = A[(size_t)(k0 + e / nb) * lda + k0 + e % nb];
-        __syncthreads();
-        if (tid < nb) rdiag[tid] = 1.0 / panel[tid * LU_LD + tid];
-        __syncthreads();
-        for (int c = tid; c < nr; c += DT) {
-            double x[LU_NB];
-#pragma unroll
-            for (int j = LU_NB - 1; j >= 0; --j) {
-                double sacc = j < nb ? Bm[(size_t)(k0 + j) * ldb + c] : 0.0;
-#pragma unroll
-                for (int i = j + 1; i < LU_NB; ++i)
-                    if (i < nb) sacc = fma(-panel[j * LU_LD + i], x[i], sacc);
-                x[j] = j < nb ? sacc * rdiag[j] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < LU_NB; ++j)
-                if (j < nb) Bm[(size_t)(k0 + j) * ldb + c] = x[j];
+        // block column k0 of U, rows 0 .. k0 + nb - 1, into the panel buffer (U11 = its last nb rows)
+        for (int e = tid; e < (k0 + nb) * LU_NB; e += DT) {
+            const int r = e >> 4, c = e & 15;
+            if (c < nb) panel[r * LU_LD + c] = A[r * lda + k0 + c];
         }
         __syncthreads();
-        if (k0 > 0)
-            wg_gemm<false, false>(lds, Bm, ldb, A + k0, lda, Bm + (size_t)k0 * ldb, ldb, k0, nr, nb, Bm, ldb, 1.0, -1.0);
+        if (tid < nb) g_rdiag[tid] = 1.0 / panel[(k0 + tid) * LU_LD + tid];
+        __syncthreads();
+        lu_trsm_upper(Bm + (size_t)k0 * ldb, ldb, k0, nb, nr, nbp, lds + us_off, usp);
+        __syncthreads();
+        RK_STAMP(5);
+        if (k0 > 0) lu_rank_update(0, k0, nb, us_off, usp, k0 >> 4, Bm, ldb, 0, 0, Bm, ldb, nr, nbp >> 4, 0, k0);
+        __syncthreads();
+        RK_STAMP(6);
     }
 }
 
@@ -401,68 +581,72 @@ __device__ __forceinline__ DenseWs carve(double* w, int p, int m) {
 }
 
 size_t dense_ws_doubles(int p, int m) {
-    return 4 * (size_t)p * p + 3 * (size_t)m * p + (size_t)m * m + 2 * (size_t)p + 2 * (size_t)m + (size_t)(p + 1) / 2 + 8;
+    return 4 * (size_t)p * p + 3 * (size_t)m * p + (size_t)m * m + 2 * (size_t)p + 2 * (size_t)m + (size_t)(p + 1) / 2 + 16;
 }
 
-// predicted moments from (mu, Sigma): A1 = Q Sigma, A2 = A1 Q^T + R, mup = Q mu      (standard.py:57-59)
-// Products with a BLOCK-DIAGONAL Q (what prior.indep_init builds: n_vars blocks of n_deriv x n_deriv): the terms a dense
-// product would add are exact zeros times finite numbers, so leaving them out changes nothing in the result (same
-// order of the remaining terms) and saves 6 p^3 of the 12.67 p^3 flops of a step.  Whether Q has that structure is
-// checked on the device once per solve (dense_qcheck_kernel); otherwise the dense GEMMs run.
-//   C = Q X (XT: X is given transposed), or C = X Q^T + E.
-// Lanes run along the output columns j (coalesced), waves along the rows i, four rows at a time with all loads issued
-// before the arithmetic; the block size is at most BD_MAX (larger blocks use the dense GEMMs).
-constexpr int BD_MAX = 8;
-
-template <bool XT>
-__device__ __forceinline__ void wg_bd_left(double* C, const double* Q, const double* X, int p, int nd) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = DT / 64;
-    for (int i0 = wave * 4; i0 < p; i0 += n_waves * 4)
-        for (int j = lane; j < p; j += 64) {
-            double q[4][BD_MAX], x[4][BD_MAX];
+// Products with a BLOCK-DIAGONAL Q (what prior.indep_init builds: n_vars blocks of nd x nd, nd = n_deriv): the terms
+// a dense product would add are exact zeros times finite numbers, so leaving them out changes nothing in the result
+// (same order of the remaining terms) and saves 6 p^3 of the 12.67 p^3 flops of a step.  Whether Q has that structure
+// is checked on the device once per solve (dense_qcheck_kernel); otherwise the dense GEMMs run.  The diagonal blocks
+// are kept in LDS (qd[i][k] = Q[i][k0(i) + k], row stride BD_MAX); a thread produces the nd outputs of one block
+// row / block column from nd loads, lanes along the contiguous direction.
+// C1 = Q X (rows of X), and, if X2T: C2 = Q X2T^T (X2T read transposed: the T^T = Q Sigma_f^T of standard.py:175)
+__device__ __noinline__ void wg_bd_left(double* C1_, const double* X_, double* C2_, const double* X2T_, int p_, int nd_) {
+    const double* const qd = g_qd;
+    double* const C1 = uni(C1_);
+    const double* const X = uni(X_);
+    double* const C2 = uni(C2_);
+    const double* const X2T = uni(X2T_);
+    const int p = uni(p_), nd = uni(nd_);
+    const int nblk = p / nd;
+    for (int e = threadIdx.x; e < nblk * p; e += DT) {
+        const int ib = e / p, j = e - ib * p, k0 = ib * nd;
+        double x[BD_MAX], xt[BD_MAX];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = min(i0 + r, p - 1), k0 = (i / nd) * nd;
-#pragma unroll
-                for (int k = 0; k < BD_MAX; ++k) {
-                    const int kk = k0 + min(k, nd - 1);
-                    q[r][k] = k < nd ? Q[(size_t)i * p + kk] : 0.0;
-                    x[r][k] = XT ? X[(size_t)j * p + kk] : X[(size_t)kk * p + j];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < BD_MAX; ++k) s = fma(q[r][k], x[r][k], s);       // (k >= nd: q = 0, x finite: exact no-ops)
-                if (i0 + r < p) C[(size_t)(i0 + r) * p + j] = s;
-            }
+        for (int k = 0; k < BD_MAX; ++k) {
+            x[k] = k < nd ? X[(size_t)(k0 + k) * p + j] : 0.0;
+            xt[k] = (X2T && k < nd) ? X2T[(size_t)j * p + k0 + k] : 0.0;
         }
+#pragma unroll
+        for (int r = 0; r < BD_MAX; ++r)
+            if (r < nd) {
+                double s = 0.0, st = 0.0;
+#pragma unroll
+                for (int k = 0; k < BD_MAX; ++k)
+                    if (k < nd) { s = fma(qd[(k0 + r) * BD_MAX + k], x[k], s); st = fma(qd[(k0 + r) * BD_MAX + k], xt[k], st); }
+                C1[(size_t)(k0 + r) * p + j] = s;
+                if (X2T) C2[(size_t)(k0 + r) * p + j] = st;
+            }
+    }
     __syncthreads();
 }
-__device__ __forceinline__ void wg_bd_right(double* C, const double* X, const double* Q, const double* E, int p, int nd) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = DT / 64;
-    for (int i0 = wave * 4; i0 < p; i0 += n_waves * 4)
-        for (int j = lane; j < p; j += 64) {
-            const int k0 = (j / nd) * nd;
-            double q[BD_MAX], x[4][BD_MAX], e[4];
+// C = X Q^T + E ; and, if D: D = F - C   (the Sigma_next - Sigma^- of standard.py:215 in the same pass)
+__device__ __noinline__ void wg_bd_right(double* C_, const double* X_, const double* E_, double* D_, const double* F_, int p_, int nd_) {
+    const double* const qd = g_qd;
+    double* const C = uni(C_);
+    const double* const X = uni(X_);
+    const double* const E = uni(E_);
+    double* const D = uni(D_);
+    const double* const F = uni(F_);
+    const int p = uni(p_), nd = uni(nd_);
+    const int nblk = p / nd;
+    for (int e = threadIdx.x; e < nblk * p; e += DT) {
+        const int i = e / nblk, jb = e - i * nblk, k0 = jb * nd;
+        double x[BD_MAX];
 #pragma unroll
-            for (int k = 0; k < BD_MAX; ++k) q[k] = k < nd ? Q[(size_t)j * p + k0 + min(k, nd - 1)] : 0.0;
+        for (int k = 0; k < BD_MAX; ++k) x[k] = k < nd ? X[(size_t)i * p + k0 + k] : 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = min(i0 + r, p - 1);
-                e[r] = E[(size_t)i * p + j];
-#pragma unroll
-                for (int k = 0; k < BD_MAX; ++k) x[r][k] = X[(size_t)i * p + k0 + min(k, nd - 1)];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < BD_MAX; ++r)
+            if (r < nd) {
                 double s = 0.0;
 #pragma unroll
-                for (int k = 0; k < BD_MAX; ++k) s = fma(x[r][k], q[k], s);
-                if (i0 + r < p) C[(size_t)(i0 + r) * p + j] = e[r] + s;
+                for (int k = 0; k < BD_MAX; ++k)
+                    if (k < nd) s = fma(x[k], qd[(k0 + r) * BD_MAX + k], s);
+                const double c = E[(size_t)i * p + k0 + r] + s;
+                C[(size_t)i * p + k0 + r] = c;
+                if (D) D[(size_t)i * p + k0 + r] = F[(size_t)i * p + k0 + r] - c;
             }
-        }
+    }
     __syncthreads();
 }
 
@@ -478,25 +662,41 @@ __global__ void dense_qcheck_kernel(const double* Q, int p, int nd, double* flag
     }
     if (mine) atomicOr(&bad, 1);
     __syncthreads();
-    if (threadIdx.x == 0) *flag = (bad || nd > BD_MAX) ? 0.0 : 1.0;
+    if (threadIdx.x == 0) *flag = (bad || nd > BD_MAX || p > BD_MAXP) ? 0.0 : 1.0;
 }
 
-// predicted moments from (mu, Sigma): A1 = Q Sigma, A2 = A1 Q^T + R, mup = Q mu      (standard.py:57-59)
-__device__ __forceinline__ void dense_predict(double* lds, const DenseArgs& a, const DenseWs& w, const double* mu, const double* Sig,
-                                              bool q_bd) {
-    const int p = a.p;
-    if (q_bd) {
-        wg_bd_left<false>(w.A1, a.Q, Sig, p, p / a.m);
-        wg_bd_right(w.A2, w.A1, a.Q, a.R, p, p / a.m);
-    } else {
-        wg_gemm<false, false>(lds, w.A1, p, a.Q, p, Sig, p, p, p, p, nullptr, 0, 0.0, 1.0);
-        wg_gemm<false, true>(lds, w.A2, p, w.A1, p, a.Q, p, p, p, p, a.R, p, 1.0, 1.0);
+__device__ __forceinline__ void load_qd(double* qd, const double* Q, int p, int nd) {
+    for (int e = threadIdx.x; e < p * BD_MAX; e += DT) {
+        const int i = e / BD_MAX, k = e - i * BD_MAX;
+        qd[e] = k < nd ? Q[(size_t)i * p + (i / nd) * nd + k] : 0.0;
     }
-    wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
+    __syncthreads();
 }
 
+// y = Q x with block-diagonal Q
+__device__ __forceinline__ void wg_bd_matvec(const double* qd, double* y, const double* x, int p, int nd) {
+    for (int i = threadIdx.x; i < p; i += DT) {
+        const int k0 = (i / nd) * nd;
+        double s = 0.0;
+        for (int k = 0; k < nd; ++k) s = fma(qd[i * BD_MAX + k], x[k0 + k], s);
+        y[i] = s;
+    }
+}
+
+__device__ __forceinline__ GemmOp gemm_op(double* C, int ldc, const double* A, int lda, bool ta, const double* B, int ldb, bool tb,
+                                          int M, int N, int K, const double* E, int lde, double ce, double cab) {
+    GemmOp g;
+    g.C = C; g.ldc = ldc; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+    g.E = E; g.lde = lde; g.ce = ce; g.cab = cab; g.ta = ta; g.tb = tb;
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward pass.  The step's dense products are issued from ONE wg_gemm instance in a descriptor loop.
+// ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[GEMM_LDS_DOUBLES];
+    double* const lds = g_lds;
+    double* const qd = g_qd;
     const int b = blockIdx.x, p = a.p, m = a.m;
     const int nd = p / m;                              // derivatives per variable: x_v = X[v * nd]
     const DenseWs w = carve(a.ws + (size_t)b * a.ws_stride, p, m);
@@ -504,6 +704,7 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
     double* mean = a.mean + (size_t)b * (a.N + 1) * p;
     double* var = a.var + (size_t)b * (a.N + 1) * p * p;
     const double* Aode = a.theta;
+    if (q_bd) load_qd(qd, a.Q, p, nd);
     // time 0: (ode_init, 0)   (solve.py:53-54, 114-121)
     for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
     for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
@@ -513,81 +714,150 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
         const double* Sig = var + (size_t)n * p * p;
         double* mu_o = mean + (size_t)(n + 1) * p;
         double* Sig_o = var + (size_t)(n + 1) * p * p;
-        dense_predict(lds, a, w, mu, Sig, q_bd);
-        // ---- interrogation (interrogate.py) for the linear ODE f = A x, x_v = X[v * nd] ----
-        for (int i = threadIdx.x; i < m; i += DT) {
-            double s = 0.0;
-            for (int v = 0; v < m; ++v) {
-                const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
-                s = fma(Aiv, w.mup[(size_t)v * nd], s);
+        // phases 0-1: predict (standard.py:57-59); 2-4: W~ Sigma-, S, (Sigma- W~^T)^T (standard.py:93-97);
+        // then the LU solve and the mean; 5: Sigma- - K (W~ Sigma-) (standard.py:101-102)
+        for (int ph = 0; ph < 6; ++ph) {
+            GemmOp g;
+            bool run = true;
+            switch (ph) {
+                case 0:
+                    if (q_bd) { wg_bd_left(w.A1, Sig, nullptr, nullptr, p, nd); run = false; }
+                    else g = gemm_op(w.A1, p, a.Q, p, false, Sig, p, false, p, p, p, nullptr, 0, 0.0, 1.0);
+                    break;
+                case 1:
+                    if (q_bd) { wg_bd_right(w.A2, w.A1, a.R, nullptr, nullptr, p, nd); run = false; }
+                    else g = gemm_op(w.A2, p, w.A1, p, false, a.Q, p, true, p, p, p, a.R, p, 1.0, 1.0);
+                    break;
+                case 2: {
+                    // ---- interrogation (interrogate.py) for the linear ODE f = A x, x_v = X[v * nd] ----
+                    if (q_bd) wg_bd_matvec(qd, w.mup, mu, p, nd);
+                    else wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
+                    for (int e = threadIdx.x; e < m * p; e += DT) {
+                        const int i = e / p, j = e % p;
+                        double Jij = 0.0;
+                        if (a.itg == RK_INTERROGATE_KRAMER && j % nd == 0) {
+                            const int v = j / nd;
+                            Jij = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+                        }
+                        w.Wt[e] = a.W[e] + (-Jij);                                   // W + wgt_meas   (solve.py:79)
+                    }
+                    __syncthreads();
+                    for (int i = threadIdx.x; i < m; i += DT) {
+                        double s = 0.0;
+                        for (int v = 0; v < m; ++v) {
+                            const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+                            s = fma(Aiv, w.mup[(size_t)v * nd], s);
+                        }
+                        // yhat = W~ mu- + a ;  a = -f (+ J mu- for kramer, interrogate.py:81-82) ; J mu- = (W - W~) mu-
+                        double jm = 0.0, wm = 0.0;
+                        for (int j = 0; j < p; ++j) {
+                            jm = fma(a.W[(size_t)i * p + j] - w.Wt[(size_t)i * p + j], w.mup[j], jm);
+                            wm = fma(w.Wt[(size_t)i * p + j], w.mup[j], wm);
+                        }
+                        const double am = a.itg == RK_INTERROGATE_KRAMER ? -s + jm : -s;
+                        w.yhat[i] = wm + am;                                         // standard.py:93
+                    }
+                    g = gemm_op(w.WS, p, w.Wt, p, false, w.A2, p, false, m, p, p, nullptr, 0, 0.0, 1.0);          // W~ Sigma-
+                    break;
+                }
+                case 3: g = gemm_op(w.S, m, w.WS, p, false, w.Wt, p, true, m, m, p, nullptr, 0, 0.0, 1.0); break;  // (W~ Sigma-) W~^T
+                case 4: g = gemm_op(w.X, p, w.Wt, p, false, w.A2, p, true, m, p, p, nullptr, 0, 0.0, 1.0); break;  // (Sigma- W~^T)^T
+                default:
+                    if (a.itg == RK_INTERROGATE_RODEO) {                              // + var_meas = W Sigma- W^T (W~ = W)
+                        for (int e = threadIdx.x; e < m * m; e += DT) w.S[e] = w.S[e] + w.S[e];
+                        __syncthreads();
+                    }
+                    wg_lu_solve(w.S, m, w.X, p, m, p, w.piv);                                                  // X = K^T (utils.py:119)
+                    for (int i = threadIdx.x; i < p; i += DT) {
+                        double s = 0.0;
+                        for (int j = 0; j < m; ++j) s = fma(w.X[(size_t)j * p + i], 0.0 - w.yhat[j], s);
+                        mu_o[i] = w.mup[i] + s;                                      // standard.py:99-100 with x_meas = 0
+                    }
+                    g = gemm_op(Sig_o, p, w.X, p, true, w.WS, p, false, p, p, m, w.A2, p, 1.0, -1.0);              // Sigma- - K (W~ Sigma-)
+                    break;
             }
-            w.f[i] = s;
+            if (run) wg_gemm(g);
         }
-        for (int e = threadIdx.x; e < m * p; e += DT) {
-            const int i = e / p, j = e % p;
-            double Jij = 0.0;
-            if (a.itg == RK_INTERROGATE_KRAMER && j % nd == 0) {
-                const int v = j / nd;
-                Jij = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
-            }
-            w.Wt[e] = a.W[e] + (-Jij);                                   // W + wgt_meas   (solve.py:79)
-        }
-        __syncthreads();
-        // yhat = W~ mu- + a ;  a = -f (+ J mu- for kramer, interrogate.py:81-82) ; J mu- = (W - W~) mu-
-        for (int i = threadIdx.x; i < m; i += DT) {
-            double jm = 0.0, wm = 0.0;
-            for (int j = 0; j < p; ++j) {
-                jm = fma(a.W[(size_t)i * p + j] - w.Wt[(size_t)i * p + j], w.mup[j], jm);
-                wm = fma(w.Wt[(size_t)i * p + j], w.mup[j], wm);
-            }
-            const double am = a.itg == RK_INTERROGATE_KRAMER ? -w.f[i] + jm : -w.f[i];
-            w.yhat[i] = wm + am;                                         // standard.py:93
-        }
-        // ---- update (standard.py:93-102) ----
-        wg_gemm<false, false>(lds, w.WS, p, w.Wt, p, w.A2, p, m, p, p, nullptr, 0, 0.0, 1.0);          // W~ Sigma-
-        wg_gemm<false, true>(lds, w.S, m, w.WS, p, w.Wt, p, m, m, p, nullptr, 0, 0.0, 1.0);            // (W~ Sigma-) W~^T
-        if (a.itg == RK_INTERROGATE_RODEO) {                              // + var_meas = W Sigma- W^T (W~ = W)
-            for (int e = threadIdx.x; e < m * m; e += DT) w.S[e] = w.S[e] + w.S[e];
-            __syncthreads();
-        }
-        wg_gemm<false, true>(lds, w.X, p, w.Wt, p, w.A2, p, m, p, p, nullptr, 0, 0.0, 1.0);            // (Sigma- W~^T)^T
-        wg_lu_solve(lds, w.S, m, w.X, p, m, p, w.piv);                                                  // X = K^T (utils.py:119)
-        for (int i = threadIdx.x; i < p; i += DT) {
-            double s = 0.0;
-            for (int j = 0; j < m; ++j) s = fma(w.X[(size_t)j * p + i], 0.0 - w.yhat[j], s);
-            mu_o[i] = w.mup[i] + s;                                      // standard.py:99-100 with x_meas = 0
-        }
-        wg_gemm<true, false>(lds, Sig_o, p, w.X, p, w.WS, p, p, p, m, w.A2, p, 1.0, -1.0);             // Sigma- - K (W~ Sigma-)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward pass (solve.py:257-301, standard.py:160-217), in place on the filtered moments.
+// ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[GEMM_LDS_DOUBLES];
+    double* const lds = g_lds;
+    double* const qd = g_qd;
     const int b = blockIdx.x, p = a.p, m = a.m;
+    const int nd = p / m;
     const DenseWs w = carve(a.ws + (size_t)b * a.ws_stride, p, m);
     const bool q_bd = a.ws[a.ws_stride - 1] != 0.0;     // set by dense_qcheck_kernel: Q is block diagonal (indep_init)
     double* mean = a.mean + (size_t)b * (a.N + 1) * p;
     double* var = a.var + (size_t)b * (a.N + 1) * p * p;
+    if (q_bd) load_qd(qd, a.Q, p, nd);
+    RK_STAMP_DECL(a.ws + a.ws_stride);
+    RK_STAMP_ZERO();
     for (int n = a.N - 1; n >= 1; --n) {
         double* mu_f = mean + (size_t)n * p;
         double* Sig_f = var + (size_t)n * p * p;
         const double* mu_s = mean + (size_t)(n + 1) * p;           // already smoothed (in place)
         const double* Sig_s = var + (size_t)(n + 1) * p * p;
-        dense_predict(lds, a, w, mu_f, Sig_f, q_bd);                    // pred[n+1] re-evaluated from filt[n]
-        if (q_bd) wg_bd_left<true>(w.A3, a.Q, Sig_f, p, p / a.m);       // T^T = Q Sigma_f^T (standard.py:175)
-        else wg_gemm<false, true>(lds, w.A3, p, a.Q, p, Sig_f, p, p, p, p, nullptr, 0, 0.0, 1.0);
-        for (int e = threadIdx.x; e < p * p; e += DT) w.A4[e] = Sig_s[e] - w.A2[e];        // Sigma_next - Sigma-
-        for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = mu_s[i] - w.mup[i];
-        __syncthreads();
-        wg_lu_solve(lds, w.A2, p, w.A3, p, p, p, w.piv);                // A3 <- G^T = solve(Sigma-, T^T)   (standard.py:176)
-        for (int i = threadIdx.x; i < p; i += DT) {
-            double s = 0.0;
-            for (int j = 0; j < p; ++j) s = fma(w.A3[(size_t)j * p + i], w.dm[j], s);
-            w.mup[i] = mu_f[i] + s;                                // standard.py:213-214 (written after the barrier)
+        // phases 0-2: pred[n+1] re-evaluated from filt[n], T^T = Q Sigma_f^T (standard.py:175), the differences;
+        // 3: G^T = solve(Sigma-, T^T) (standard.py:176), mean (213-214), G D; 4: Sigma_f + (G D) G^T (215-216)
+        for (int ph = 0; ph < 5; ++ph) {
+            GemmOp g;
+            bool run = true;
+            switch (ph) {
+                case 0:
+                    if (q_bd) { wg_bd_left(w.A1, Sig_f, w.A3, Sig_f, p, nd); run = false; }
+                    else g = gemm_op(w.A1, p, a.Q, p, false, Sig_f, p, false, p, p, p, nullptr, 0, 0.0, 1.0);
+                    break;
+                case 1:
+                    if (q_bd) { wg_bd_right(w.A2, w.A1, a.R, w.A4, Sig_s, p, nd); run = false; }
+                    else g = gemm_op(w.A2, p, w.A1, p, false, a.Q, p, true, p, p, p, a.R, p, 1.0, 1.0);
+                    break;
+                case 2:
+                    if (q_bd) { run = false; break; }
+                    for (int e = threadIdx.x; e < p * p; e += DT) w.A4[e] = Sig_s[e] - w.A2[e];        // Sigma_next - Sigma-
+                    g = gemm_op(w.A3, p, a.Q, p, false, Sig_f, p, true, p, p, p, nullptr, 0, 0.0, 1.0);
+                    break;
+                case 3: {
+                    if (q_bd) wg_bd_matvec(qd, w.mup, mu_f, p, nd);
+                    else wg_gemv<false>(w.mup, a.Q, p, mu_f, p, p, nullptr, 0.0, 1.0);
+                    __syncthreads();
+                    for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = mu_s[i] - w.mup[i];
+                    __syncthreads();
+                    RK_STAMP(0);
+                    wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv, a.ws + a.ws_stride);   // A3 <- G^T
+                    RK_STAMP_RESET();
+                    // mean: mu_f + G dm, the column sums of G^T split over the workgroup (partial sums through LDS)
+                    {
+                        const int ng = DT / 64;                                     // row groups of G^T
+                        for (int i = threadIdx.x & 63; i < p; i += 64) {
+                            const int gq = threadIdx.x >> 6;
+                            double s = 0.0;
+                            for (int j = gq; j < p; j += ng) s = fma(w.A3[(size_t)j * p + i], w.dm[j], s);
+                            lds[gq * p + i] = s;
+                        }
+                        __syncthreads();
+                        for (int i = threadIdx.x; i < p; i += DT) {
+                            double s = 0.0;
+                            for (int gq = 0; gq < ng; ++gq) s += lds[gq * p + i];
+                            mu_f[i] = mu_f[i] + s;                                   // standard.py:213-214
+                        }
+                        __syncthreads();
+                    }
+                    RK_STAMP(7);
+                    g = gemm_op(w.A1, p, w.A3, p, true, w.A4, p, false, p, p, p, nullptr, 0, 0.0, 1.0);    // G D
+                    break;
+                }
+                default:
+                    RK_STAMP(8);
+                    g = gemm_op(Sig_f, p, w.A1, p, false, w.A3, p, false, p, p, p, Sig_f, p, 1.0, 1.0);    // Sigma_f + (G D) G^T
+                    break;
+            }
+            if (run) wg_gemm(g);
         }
-        wg_gemm<true, false>(lds, w.A1, p, w.A3, p, w.A4, p, p, p, p, nullptr, 0, 0.0, 1.0);    // G D
-        for (int i = threadIdx.x; i < p; i += DT) mu_f[i] = w.mup[i];
-        wg_gemm<false, false>(lds, Sig_f, p, w.A1, p, w.A3, p, p, p, p, Sig_f, p, 1.0, 1.0);    // Sigma_f + (G D) G^T (standard.py:215-216)
+        RK_STAMP(9);
     }
 }
 
