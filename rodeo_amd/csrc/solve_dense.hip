@@ -69,7 +69,7 @@ __shared__ __attribute__((aligned(16))) double g_lds[LDS_DOUBLES];
 constexpr int LU_NB = 16, LU_MAXN = 320, LU_LD = LU_NB + 1;
 constexpr int BD_MAX = 8, BD_MAXP = 320;
 __shared__ int g_ppiv[LU_NB], g_cur[LU_MAXN], g_mlist[2 * LU_NB], g_mcount;
-__shared__ double g_rdiag[LU_NB];
+__shared__ double g_rdiag[LU_NB], g_rowbuf[2 * LU_NB];
 __shared__ double g_qd[BD_MAXP * BD_MAX];         // diagonal blocks of a block-diagonal Q
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -328,50 +328,87 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return m;
 }
 
-// wave 0: factor the LDS panel (rows x nb, row stride LU_LD) in place; ppiv[j] = pivot row of column j (panel-relative);
-// cur[r] = the original (panel-relative) row that ends up in position r.
-__device__ __noinline__ void lu_panel_wave(int rows_, int nb_) {
-    double* const panel = g_lds;
-    int* const ppiv = g_ppiv;
-    int* const cur = g_cur;
-    const int rows = uni(rows_), nb = uni(nb_);
-    const int l = threadIdx.x;                             // lane of wave 0
-    for (int j = 0; j < nb; ++j) {
-        double best = -1.0;
-        int bi = 0x7fffffff;
-        for (int r = l; r < rows; r += 64)
-            if (r >= j) {
-                const double v = fabs(panel[r * LU_LD + j]);
-                if (v > best) { best = v; bi = r; }         // ascending rows per lane: its first maximum
-            }
-        const double m = wave_max_f64(best);
-        int pj = wave_min_i32(best == m ? bi : 0x7fffffff);
-        if (pj == 0x7fffffff) pj = j;                       // (all NaN: keep the row, like an unlucky getrf)
-        if (l == 0) {
-            ppiv[j] = pj;
-            const int t = cur[j]; cur[j] = cur[pj]; cur[pj] = t;
-        }
-        if (l < nb && pj != j) {
-            const double t = panel[j * LU_LD + l];
-            panel[j * LU_LD + l] = panel[pj * LU_LD + l];
-            panel[pj * LU_LD + l] = t;
-        }
-        wave_lds_sync();
-        double prow[LU_NB];
+// wave 0: factor the LDS panel (rows x nb, row stride LU_LD) in place; g_ppiv[j] = pivot row of column j
+// (panel-relative); g_cur[r] = the original (panel-relative) row that ends up in position r.
+// Lane l keeps rows l, l + 64, ... (RS of them) in registers for the whole panel and the rows never move: each row
+// carries its current POSITION (what LAPACK's interchanges would have made of it), the pivot search is "largest |.|,
+// smallest position" (DPP row reductions + readlane), an interchange swaps two positions, the pivot row is broadcast
+// through a 16-double LDS buffer, the rank-1 update runs on the rows whose position is still below the diagonal, and
+// the rows are written back to the panel AT their positions.  The 16 columns are unrolled through templates, so
+// every register index is a constant (with `if (s == ps)` selections hipcc makes the index dynamic and moves the
+// rows to scratch).
+template <int RS, int J>
+__device__ __forceinline__ void lu_panel_col(double (&a)[RS][LU_NB], int (&pos)[RS], int l) {
+    double* const buf = g_rowbuf;
+    double best = -1.0;
+    int bp = 0x7fffffff;
 #pragma unroll
-        for (int c = 0; c < LU_NB; ++c) prow[c] = panel[j * LU_LD + c];
-        const double rinv = 1.0 / panel[j * LU_LD + j];
-        for (int r = l; r < rows; r += 64)
-            if (r > j) {
-                const double lm = panel[r * LU_LD + j] * rinv;
-                panel[r * LU_LD + j] = lm;
+    for (int s = 0; s < RS; ++s) {
+        const double v = fabs(a[s][J]);
+        if (pos[s] >= J && pos[s] != 0x7fffffff && (v > best || (v == best && pos[s] < bp))) { best = v; bp = pos[s]; }
+    }
+    const double m = wave_max_f64(best);
+    int pj = wave_min_i32(best == m ? bp : 0x7fffffff);     // first maximum in LAPACK's row order
+    if (pj == 0x7fffffff) pj = J;                           // (all NaN: keep the row, like an unlucky getrf)
+    if (l == 0) g_ppiv[J] = pj;
 #pragma unroll
-                for (int c = 1; c < LU_NB; ++c)
-                    if (c > j && c < nb) panel[r * LU_LD + c] = fma(-lm, prow[c], panel[r * LU_LD + c]);
-            }
-        wave_lds_sync();
+    for (int s = 0; s < RS; ++s) {
+        if (pos[s] == pj) {                                 // the pivot row's owner publishes it
+#pragma unroll
+            for (int c = 0; c < LU_NB; ++c) buf[c] = a[s][c];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < RS; ++s) pos[s] = pos[s] == J ? pj : (pos[s] == pj ? J : pos[s]);      // interchange J <-> pj
+    wave_lds_sync();
+    double prow[LU_NB];
+#pragma unroll
+    for (int c = J; c < LU_NB; ++c) prow[c] = buf[c];
+    wave_lds_sync();                                        // the buffer is free for the next column
+    const double rinv = 1.0 / prow[J];
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+        if (pos[s] > J && pos[s] != 0x7fffffff) {
+            const double lm = a[s][J] * rinv;
+            a[s][J] = lm;
+#pragma unroll
+            for (int c = J + 1; c < LU_NB; ++c) a[s][c] = fma(-lm, prow[c], a[s][c]);     // (columns >= nb: unused)
+        }
     }
 }
+template <int RS, int J>
+__device__ __forceinline__ void lu_panel_cols(double (&a)[RS][LU_NB], int (&pos)[RS], int nb, int l) {
+    if constexpr (J < LU_NB) {
+        if (J < nb) lu_panel_col<RS, J>(a, pos, l);
+        lu_panel_cols<RS, J + 1>(a, pos, nb, l);
+    }
+}
+template <int RS>
+__device__ __forceinline__ void lu_panel_regs(int rows, int nb) {
+    double* const panel = g_lds;
+    const int l = threadIdx.x;                             // lane of wave 0
+    double a[RS][LU_NB];
+    int pos[RS];
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+        pos[s] = (l + 64 * s < rows) ? l + 64 * s : 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < LU_NB; ++c) a[s][c] = (l + 64 * s < rows) ? panel[(l + 64 * s) * LU_LD + c] : 0.0;
+    }
+    wave_lds_sync();                                        // every row is in registers before any is written back
+    lu_panel_cols<RS, 0>(a, pos, nb, l);
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+        if (pos[s] != 0x7fffffff) {
+            g_cur[pos[s]] = l + 64 * s;
+#pragma unroll
+            for (int c = 0; c < LU_NB; ++c) panel[pos[s] * LU_LD + c] = a[s][c];
+        }
+    }
+}
+
+__device__ __noinline__ void lu_panel_wave3(int rows_, int nb_) { lu_panel_regs<3>(uni(rows_), uni(nb_)); }   // rows <= 192
+__device__ __noinline__ void lu_panel_wave5(int rows_, int nb_) { lu_panel_regs<5>(uni(rows_), uni(nb_)); }   // rows <= 320
 
 // rank-16 update  C <- C - L U  for the tiles (rb, ct): rows r0 + 16 rb.., a strip of column tiles; L rows from the LDS
 // panel `lp` (row stride LU_LD, row index rb * 16 + i, columns < nb), U from the LDS strip `us` (row stride usp).
@@ -512,7 +549,7 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         for (int r = tid; r < rows; r += DT) g_cur[r] = r;
         if (tid == 0) g_mcount = 0;
         __syncthreads();
-        if (tid < 64) lu_panel_wave(rows, nb);
+        if (tid < 64) { if (rows <= 192) lu_panel_wave3(rows, nb); else lu_panel_wave5(rows, nb); }
         __syncthreads();
         RK_STAMP(1);
         // the diagonal block back to A (its upper triangle is U11, needed by the back substitution); pivots
