@@ -1,19 +1,37 @@
 // Dense large-block solver (BASELINE config 5: the "non-block" form of src/rodeo/prior/indep_init.py:8-23 -- one
 // dense block of n_vars * n_deriv states with n_bmeas = n_vars measurements; examples/solve_nb.py:55-260 is the
-// reference's own statement of this path).  One 256-thread workgroup per trajectory runs the whole time loop of
+// reference's own statement of this path).  One 512-thread workgroup (8 waves, one per CU) per trajectory runs the
+// whole time loop of
 //   src/rodeo/solve.py:31-122 (forward)  and  src/rodeo/solve.py:257-301 (backward mean/variance smoother)
-// with every p x p operand in global memory (the per-trajectory working set, ~1 MB at p = 160, stays in L2 / the
-// Infinity Cache) and register-tiled fp64 GEMMs; all LU solves use partial pivoting like src/rodeo/utils.py:119.
+// with every p x p operand in global memory and fp64 MFMA products; all LU solves use partial pivoting like
+// src/rodeo/utils.py:119.
 //
 // Layout: trajectory-major = the reference's own layout with a leading batch axis:
 //   mean (B, N+1, p), var (B, N+1, p, p)  (n_block = 1), so a workgroup streams contiguous p x p matrices.
 //
-// GEMMs: v_mfma_f64_16x16x4_f64 with op(B) staged through LDS (wg_gemm); LU: blocked, panels of 16 columns in LDS,
-// trailing and right-hand-side updates through wg_gemm.  Measured on C5 (B = 256, p = 160, m = 32): 8.9 % of the fp64
-// peak on the reference algorithm's flop count; what remains is the panel factorisation's barrier chain and the
-// thread-per-column triangular solves / row interchanges (a register-row panel variant was tried and was not faster).
-// Every helper is force-inlined: with real calls the 400+ VGPR frames made hipcc's callee-saved spills fault at run
-// time (found the hard way).
+// Structure (what made it 2.1x faster than the first version, which inlined a templated GEMM at every call site and
+// ran one wave per SIMD):
+//   * ONE instance of every building block.  The kernels are descriptor loops over a step's phases; wg_gemm,
+//     wg_lu_solve, the rank-16 update, the panel factorisation and the block-diagonal products are real (non-inlined)
+//     functions.  Their arguments arrive in VGPRs, so every uniform one is made scalar again (uni()), and the LDS is a
+//     file-scope array (through a pointer argument it would be addressed with flat loads).  Kernel code: 8 KB.
+//   * wg_gemm: both operands staged through LDS in k-chunks of 32 (a transposed operand only changes its staging),
+//     16 x 16 tiles of v_mfma_f64_16x16x4_f64, accumulators in registers across the chunks.
+//   * wg_lu_solve: right-looking, 16-column panels.  Panel: wave 0 alone, rows in registers, each row carries its
+//     LAPACK position (no physical interchanges), pivot search by DPP reductions, pivot row broadcast through LDS.
+//     The panel's net row permutation is applied to the trailing columns and right-hand sides in one pass (one
+//     thread per column).  Triangular solves thread-per-column from the LDS panel; trailing matrix AND right-hand
+//     sides updated by rank-16 MFMA tiles whose A fragments come from the LDS panel and B fragments from an LDS strip.
+//   * products with the block-diagonal Q of prior.indep_init skip their exact-zero terms (checked on the device).
+// hipcc pitfalls met here: `if (s == runtime_slot)` selections over a register array become a dynamic index and
+// move the array to scratch (use selects / per-row state); all 120 LDS reads of a 16 x 16 triangular solve are issued
+// up front and spill unless each row's reads are tied to the previous result; a spill reload in a loop costs an
+// s_waitcnt vmcnt(0), i.e. it serialises every outstanding global load.
+// Measured on C5 (B = 256, p = 160, m = 32): 101 -> 48 ms per 50 steps = 19 % of the fp64 peak on the reference
+// algorithm's flop count.  The phases now run at the chip's memory limit: a step moves ~8 MB per trajectory (the LU's
+// ten trailing updates alone 3 MB), 2 GB over the 256 workgroups, far beyond the L2s; the rank-16 updates reach
+// 7 TB/s aggregate.  Next step would be an LU whose [Sigma^- | T^T] stays in registers (200 tiles over 8 waves).
+// Phase timing: build with -DRK_DENSE_STAMPS, run scripts/bench_configs.py c5 with RK_DENSE_STAMPS=1.
 #include "common.hpp"
 #include "linalg_small.hpp"
 #include "solve_args.hpp"
@@ -424,32 +442,62 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
     double* const C2 = uni(C2_);
     const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
     const int nct = ctA + ctB, tiles = rt * nct;
-    for (int e = wave; e < tiles; e += NWAVE) {
-        const int rb = e / nct, ct = e - rb * nct;
+    // Tiles wave, wave + 8, ... in groups of RU_G: the C values of the NEXT group are loaded before the current group is
+    // multiplied and stored (a tile is 4 loads, 4 MFMAs, 4 stores; without this every tile waits a full memory round trip).
+    constexpr int RU_G = 4;
+    auto tile_of = [&](int e, double*& Cm, int& ld, int& cj, int& sj, int& rb, bool& cok) {
+        rb = e / nct;
+        const int ct = e - rb * nct;
         const bool inA = ct < ctA;
-        double* const Cm = inA ? C1 : C2;
-        const int ld = inA ? ld1 : ld2, ncol = inA ? n1 : n2;
-        const int cj = (inA ? ct : ct - ctA) * 16 + lo, sj = (inA ? ct * 16 : offB + (ct - ctA) * 16) + lo;
-        const bool cok = cj < ncol;
-        d4 acc;
+        Cm = inA ? C1 : C2;
+        ld = inA ? ld1 : ld2;
+        cj = (inA ? ct : ct - ctA) * 16 + lo;
+        sj = (inA ? ct * 16 : offB + (ct - ctA) * 16) + lo;
+        cok = cj < (inA ? n1 : n2);
+    };
+    auto load_group = [&](int e0, d4 (&c)[RU_G]) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int ii = rb * 16 + 4 * v + hi;
-            acc[v] = (cok && ii < mrows) ? Cm[ii * ld + cj] : 0.0;
-        }
-        const int li = min(rb * 16 + lo, lrows - 1);
+        for (int u = 0; u < RU_G; ++u) {
+            const int e = e0 + u * NWAVE;
+            if (e < tiles) {
+                double* Cm; int ld, cj, sj, rb; bool cok;
+                tile_of(e, Cm, ld, cj, sj, rb, cok);
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            const int k = 4 * kq + hi;
-            const double a = k < nb ? -lp[li * LU_LD + k] : 0.0;
-            const double b = us[k * usp + sj];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                for (int v = 0; v < 4; ++v) {
+                    const int ii = rb * 16 + 4 * v + hi;
+                    c[u][v] = (cok && ii < mrows) ? Cm[ii * ld + cj] : 0.0;
+                }
+            }
+        }
+    };
+    d4 cur[RU_G], nxt[RU_G];
+    load_group(wave, cur);
+    for (int e0 = wave; e0 < tiles; e0 += RU_G * NWAVE) {
+        load_group(e0 + RU_G * NWAVE, nxt);
+#pragma unroll
+        for (int u = 0; u < RU_G; ++u) {
+            const int e = e0 + u * NWAVE;
+            if (e < tiles) {
+                double* Cm; int ld, cj, sj, rb; bool cok;
+                tile_of(e, Cm, ld, cj, sj, rb, cok);
+                const int li = min(rb * 16 + lo, lrows - 1);
+                d4 acc = cur[u];
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int k = 4 * kq + hi;
+                    const double a = k < nb ? -lp[li * LU_LD + k] : 0.0;
+                    const double b = us[k * usp + sj];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int ii = rb * 16 + 4 * v + hi;
+                    if (cok && ii < mrows) Cm[ii * ld + cj] = acc[v];
+                }
+            }
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int ii = rb * 16 + 4 * v + hi;
-            if (cok && ii < mrows) Cm[ii * ld + cj] = acc[v];
-        }
+        for (int u = 0; u < RU_G; ++u) cur[u] = nxt[u];
     }
 }
 
@@ -532,6 +580,7 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
     double* const Bm = uni(Bm_);
     int* const piv = uni(piv_);
     double* const ws_end = uni(ws_end_);
+    (void)ws_end;
     const int lda = uni(lda_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
     RK_STAMP_DECL(ws_end);
     const int nrp = (n + 15) & ~15, nbp = (nr + 15) & ~15;      // strip: [0, nrt) trailing columns, [nrt, nrt + nbp) right-hand sides
@@ -635,25 +684,36 @@ __device__ __noinline__ void wg_bd_left(double* C1_, const double* X_, double* C
     double* const C2 = uni(C2_);
     const double* const X2T = uni(X2T_);
     const int p = uni(p_), nd = uni(nd_);
-    const int nblk = p / nd;
-    for (int e = threadIdx.x; e < nblk * p; e += DT) {
-        const int ib = e / p, j = e - ib * p, k0 = ib * nd;
-        double x[BD_MAX], xt[BD_MAX];
+    const int nblk = p / nd, total = nblk * p;
+    constexpr int U = 2;                                   // items per pass: all their loads are issued before the arithmetic
+    for (int e0 = threadIdx.x; e0 < total; e0 += U * DT) {
+        double x[U][BD_MAX], xt[U][BD_MAX];
 #pragma unroll
-        for (int k = 0; k < BD_MAX; ++k) {
-            x[k] = k < nd ? X[(size_t)(k0 + k) * p + j] : 0.0;
-            xt[k] = (X2T && k < nd) ? X2T[(size_t)j * p + k0 + k] : 0.0;
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u * DT, total - 1), ib = e / p, j = e - ib * p, k0 = ib * nd;
+#pragma unroll
+            for (int k = 0; k < BD_MAX; ++k) {
+                x[u][k] = k < nd ? X[(k0 + k) * p + j] : 0.0;
+                xt[u][k] = (X2T && k < nd) ? X2T[j * p + k0 + k] : 0.0;
+            }
         }
 #pragma unroll
-        for (int r = 0; r < BD_MAX; ++r)
-            if (r < nd) {
-                double s = 0.0, st = 0.0;
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * DT;
+            if (e < total) {
+                const int ib = e / p, j = e - ib * p, k0 = ib * nd;
 #pragma unroll
-                for (int k = 0; k < BD_MAX; ++k)
-                    if (k < nd) { s = fma(qd[(k0 + r) * BD_MAX + k], x[k], s); st = fma(qd[(k0 + r) * BD_MAX + k], xt[k], st); }
-                C1[(size_t)(k0 + r) * p + j] = s;
-                if (X2T) C2[(size_t)(k0 + r) * p + j] = st;
+                for (int r = 0; r < BD_MAX; ++r)
+                    if (r < nd) {
+                        double s = 0.0, st = 0.0;
+#pragma unroll
+                        for (int k = 0; k < BD_MAX; ++k)
+                            if (k < nd) { s = fma(qd[(k0 + r) * BD_MAX + k], x[u][k], s); st = fma(qd[(k0 + r) * BD_MAX + k], xt[u][k], st); }
+                        C1[(k0 + r) * p + j] = s;
+                        if (X2T) C2[(k0 + r) * p + j] = st;
+                    }
             }
+        }
     }
     __syncthreads();
 }
@@ -666,23 +726,38 @@ __device__ __noinline__ void wg_bd_right(double* C_, const double* X_, const dou
     double* const D = uni(D_);
     const double* const F = uni(F_);
     const int p = uni(p_), nd = uni(nd_);
-    const int nblk = p / nd;
-    for (int e = threadIdx.x; e < nblk * p; e += DT) {
-        const int i = e / nblk, jb = e - i * nblk, k0 = jb * nd;
-        double x[BD_MAX];
+    const int nblk = p / nd, total = nblk * p;
+    constexpr int U = 2;
+    for (int e0 = threadIdx.x; e0 < total; e0 += U * DT) {
+        double x[U][BD_MAX], ev[U][BD_MAX], fv[U][BD_MAX];
 #pragma unroll
-        for (int k = 0; k < BD_MAX; ++k) x[k] = k < nd ? X[(size_t)i * p + k0 + k] : 0.0;
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u * DT, total - 1), i = e / nblk, jb = e - i * nblk, k0 = jb * nd;
 #pragma unroll
-        for (int r = 0; r < BD_MAX; ++r)
-            if (r < nd) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < BD_MAX; ++k)
-                    if (k < nd) s = fma(x[k], qd[(k0 + r) * BD_MAX + k], s);
-                const double c = E[(size_t)i * p + k0 + r] + s;
-                C[(size_t)i * p + k0 + r] = c;
-                if (D) D[(size_t)i * p + k0 + r] = F[(size_t)i * p + k0 + r] - c;
+            for (int k = 0; k < BD_MAX; ++k) {
+                x[u][k] = k < nd ? X[i * p + k0 + k] : 0.0;
+                ev[u][k] = k < nd ? E[i * p + k0 + k] : 0.0;
+                fv[u][k] = (D && k < nd) ? F[i * p + k0 + k] : 0.0;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * DT;
+            if (e < total) {
+                const int i = e / nblk, jb = e - i * nblk, k0 = jb * nd;
+#pragma unroll
+                for (int r = 0; r < BD_MAX; ++r)
+                    if (r < nd) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int k = 0; k < BD_MAX; ++k)
+                            if (k < nd) s = fma(x[u][k], qd[(k0 + r) * BD_MAX + k], s);
+                        const double c = ev[u][r] + s;
+                        C[i * p + k0 + r] = c;
+                        if (D) D[i * p + k0 + r] = fv[u][r] - c;
+                    }
+            }
+        }
     }
     __syncthreads();
 }
@@ -732,7 +807,6 @@ __device__ __forceinline__ GemmOp gemm_op(double* C, int ldc, const double* A, i
 // Forward pass.  The step's dense products are issued from ONE wg_gemm instance in a descriptor loop.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
-    double* const lds = g_lds;
     double* const qd = g_qd;
     const int b = blockIdx.x, p = a.p, m = a.m;
     const int nd = p / m;                              // derivatives per variable: x_v = X[v * nd]
@@ -822,8 +896,8 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
 // Backward pass (solve.py:257-301, standard.py:160-217), in place on the filtered moments.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
-    double* const lds = g_lds;
     double* const qd = g_qd;
+    double* const lds = g_lds;
     const int b = blockIdx.x, p = a.p, m = a.m;
     const int nd = p / m;
     const DenseWs w = carve(a.ws + (size_t)b * a.ws_stride, p, m);
@@ -872,6 +946,7 @@ __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
                         for (int i = threadIdx.x & 63; i < p; i += 64) {
                             const int gq = threadIdx.x >> 6;
                             double s = 0.0;
+                            #pragma unroll 8
                             for (int j = gq; j < p; j += ng) s = fma(w.A3[(size_t)j * p + i], w.dm[j], s);
                             lds[gq * p + i] = s;
                         }
