@@ -28,6 +28,19 @@ __device__ __forceinline__ double fast_rcp_cubic(double x) {
     return fma(y0, fma(e, e, e), y0);
 }
 
+// sqrt(x) for x >= 0 in the normal range (variances), from v_rsq_f64 and two coupled Goldschmidt / Newton steps:
+// eight dependent operations, no scaling branches (what sqrt() adds for denormal / huge arguments); <= 1 ulp.
+__device__ __forceinline__ double fast_sqrt_pos(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x > 0.0 ? g : 0.0;
+}
+
 // C = A (RxK) * B (KxC)
 template <int R, int K, int C>
 __device__ __forceinline__ void mm(const double (&A)[R][K], const double (&B)[K][C], double (&out)[R][C]) {

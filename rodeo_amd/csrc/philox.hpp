@@ -45,10 +45,18 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t traj, uint32
     uint32_t r[4];
     philox4x32_10(traj, step, block | (purpose << 16), chunk, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     const double u1 = u53(r[0], r[1]), u2 = u53(r[2], r[3]);
-    const double rad = sqrt(-2.0 * log(u1));
-    const double th = (2.0 * 3.14159265358979323846) * u2;
+    // sqrt without the scaling branches of sqrt() (the argument is in [1.1e-16, 74]); sin / cos of 2 pi u2 through
+    // sincospi: exact range reduction instead of the generic large-argument path of sincos() -- together about half
+    // the instructions; the results differ from the NumPy mirror's cos(fl(2 pi u2)) by the rounding of the angle (1e-16)
+    const double t = -2.0 * log(u1);
+    const double rs = __builtin_amdgcn_rsq(t);
+    double g = t * rs, h = 0.5 * rs;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double rad = fma(fma(-g, g, t), h, g);
     double s, c;
-    sincos(th, &s, &c);
+    sincospi(2.0 * u2, &s, &c);
     z0 = rad * c;
     z1 = rad * s;
 }

@@ -160,6 +160,44 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
 #undef RK_AFTER
         return;
     }
+    if constexpr (rhs_has_tile_form<RHS>::value && D == 2 && ITG == RK_INTERROGATE_CHKREBTII) {
+        // The pseudo-marginal path (BASELINE config 4).  interrogate_chkrebtii has no Jacobian term (wgt_meas = 0), so the
+        // measurement row is the constant W and NONE of the step's MFMAs depends on the draw: all seven are issued back to
+        // back (U, M-, M-^T, row 0 of M-, Sigma- W^T, W Sigma-, S), and the draw x_0 = mu-_0 + sqrt(Sigma-_00) z_0
+        // (interrogate.py:22-34), f(x) and the offset a = -f only touch column 3 of [W Sigma- | W mu- + a] afterwards.
+        // (Tried: a second wave per workgroup that only draws the normals into a double-buffered LDS array -- no gain, the
+        // step is bound by its dependent VALU chain (sqrt, cubic, reciprocal), not by the generator.)
+        double tk[6];
+        RHS::tile_consts(blk, th, tk);
+        const double ac3 = -tk[1], ac1 = -tk[0], aco = -tk[2], ac0 = -tk[3];      // a = -f as the cubic of the generic path's row 3
+        const double e3c = c == 3 ? 1.0 : 0.0;
+        for (int n = 0; n < a.N; ++n) {
+            // z_0 of this step first: its LDS latency hides behind the MFMAs
+            if ((n & 15) == 0) {                            // the 16 lanes of a tile draw z_0 for 16 consecutive steps
+                double z0, z1;
+                normal_pair(a.seed, traj, (uint32_t)(n + r * 4 + c), (uint32_t)blk, PURPOSE_INTERROGATE, 0u, z0, z1);
+                zbuf[tc.g * 16 + r * 4 + c] = z0;
+            }
+            const double zn = zbuf[tc.g * 16 + (n & 15)];
+            const double U = MF(M, Qt, 0.0);
+            const double Mp = MF(U, Qt, Rt);
+            const double MpT = MF(Qt0, U, RtT);
+            const double R0 = MF(E0, Mp, 0.0);              // row 0 of M- in every row: [Sigma-_00 .. | mu-_0]
+            const double Z0 = MF(MpT, Wr, 0.0);             // Sigma- W^T                          (standard.py:97)
+            const double WS0 = MF(Wr, Mp, 0.0);             // [W Sigma- | W mu-]
+            double S = MF(Z0, Wr, 0.0);
+            S = S + S;                                      // + var_meas = W Sigma- W^T            (interrogate.py:26-29)
+            const double v_own = fma(fast_sqrt_pos(quad_bcast0(R0)), zn, quad_bcast3(R0));
+            const double v_oth = pair_other_quad_uniform(v_own);
+            const double am = fma(fma(fma(ac3, v_own, 0.0), v_own, ac1), v_own, fma(aco, v_oth, ac0));     // mean_meas = -f(x, t)
+            const double WS = fma(e3c, am, WS0);            // yhat = W mu- + a in column 3         (standard.py:93)
+            const double PW = Z0 * WS;
+            M = fma(-PW, fast_rcp_cubic(S), Mp);            // standard.py:98-102
+            row += tstride_all * sizeof(double);
+            store_row(M);
+        }
+        return;
+    }
     for (int n = 0; n < a.N; ++n) {
         // ---- predict (standard.py:57-59): U = (Q~ M)^T, M- = Q~ M Q~^T + R~; B0 = row 0 of Q~ M in every row ----
         // (a 4x4x4 fp64 MFMA blocks this wave's issue for ~17 cycles = 4 fp64 VALU ops, and nothing overlaps it --

@@ -39,15 +39,25 @@ def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10
     else:
         layout = plan.layout
         state = plan.var_state if layout in (_lib.LAYOUT_TILE3, _lib.LAYOUT_TILE4) else plan.mean_state
-    d_obs, d_ind = dev.to_device(obs), dev.to_device(ind)
+    # observations / indices / output live on the plan and are re-uploaded only when they change (a pseudo-marginal
+    # chain calls this once per step with the same data): per call one upload (upars) and one kernel
+    cache = plan.__dict__.setdefault("_logpost_cache", {})
+    sig = (obs.shape, obs.tobytes(), ind.tobytes())
+    if cache.get("sig") != sig:
+        cache["sig"], cache["obs"], cache["ind"] = sig, dev.to_device(obs), dev.to_device(ind)
+    d_obs, d_ind = cache["obs"], cache["ind"]
     d_up, k = None, 0
     if upars is not None:
         up = np.asarray(upars, dtype=np.float64)
         k = up.shape[1] if n_prior is None else int(n_prior)
-        d_up = dev.to_device(np.ascontiguousarray(up[:, :k].T))
+        upt = np.ascontiguousarray(up[:, :k].T)
+        d_up = cache.get("up")
+        if d_up is None or tuple(d_up.shape) != upt.shape:
+            d_up = cache["up"] = dev.to_device(upt)
+        else:
+            d_up.upload(upt)
     out = dev.empty((plan.B,))
     _lib.check(dev.lib.rk_gauss_obs_logpost(dev.h, plan.B, plan.N, plan.d, plan.p, layout, state.ptr, d_obs.ptr,
                                             d_ind.ptr, ind.shape[0], float(noise_sd),
                                             d_up.ptr if d_up is not None else None, k, float(prior_sd), out.ptr))
-    out._keep = (d_obs, d_ind, d_up)          # keep inputs alive until the stream has run the kernel
     return out
