@@ -132,3 +132,41 @@ def test_config5_full_size_properties(ra):
     fo = scan.solve_filter(None, ode_o, W, X0[:3], 0.0, 4.0 / N, 4, oi.interrogate_kramer, *prior)
     mfo = fo["state_filt"][0]
     assert np.max(np.abs(mf - mfo) / np.maximum(np.max(np.abs(mfo), axis=(0, 1, 2)), 1e-300)) < 1e-6
+
+
+@pytest.mark.parametrize("n_vars,n_deriv,N", [(40, 5, 3), (66, 5, 2), (44, 4, 3)])
+def test_dense_large_blocks(ra, n_vars, n_deriv, N):
+    """
+    p = 200 and 176 (GEMM macro-blocks beyond 160 x 160, LU panels with five register rows per lane) and p = 330 (LU
+    beyond the blocked solver's limit: unblocked fallback) against the oracle, interrogate_rodeo, a few steps.
+    """
+    t_max, B = N / 24.0, 2
+    s = dense_problem(ra, n_vars, n_deriv, N, t_max, B=B)
+    ode_d, ode_o = ra.ode.linear_dense(n_vars, n_deriv), odes.make_linear_dense(s["A"], n_deriv)
+    plan = ra.SolvePlan(ode_d, s["W"], s["x0"], 0.0, t_max, N, ra.interrogate.interrogate_rodeo, s["prior"], A=s["A"])
+    plan.mv(None)
+    m, v = plan.state_host()
+    mo, vo = scan.solve_mv(None, ode_o, s["W"], s["x0"], 0.0, t_max, N, oi.interrogate_rodeo, s["prior"])
+    scale_m = np.max(np.abs(mo), axis=(0, 1, 2))
+    assert np.max(np.abs(m - mo) / np.maximum(scale_m, 1e-300)) < 1e-8
+    dv = np.sqrt(np.abs(np.einsum("bnkii->bnki", vo)).max(axis=(0, 1, 2)))
+    assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :] + 1e-300)) < 1e-6
+
+
+def test_dense_general_prior_weight(ra):
+    """A prior weight matrix that is NOT block diagonal takes the dense-GEMM predict path (no skipped terms)."""
+    n_vars, n_deriv, N = 6, 3, 12
+    t_max, B = N / 24.0, 3
+    s = dense_problem(ra, n_vars, n_deriv, N, t_max, B=B)
+    rng = np.random.default_rng(5)
+    Q, R = s["prior"]
+    Q = Q + 1e-3 * rng.standard_normal(Q.shape)
+    ode_d, ode_o = ra.ode.linear_dense(n_vars, n_deriv), odes.make_linear_dense(s["A"], n_deriv)
+    plan = ra.SolvePlan(ode_d, s["W"], s["x0"], 0.0, t_max, N, ra.interrogate.interrogate_rodeo, (Q, R), A=s["A"])
+    plan.mv(None)
+    m, v = plan.state_host()
+    mo, vo = scan.solve_mv(None, ode_o, s["W"], s["x0"], 0.0, t_max, N, oi.interrogate_rodeo, (Q, R))
+    scale_m = np.max(np.abs(mo), axis=(0, 1, 2))
+    assert np.max(np.abs(m - mo) / np.maximum(scale_m, 1e-300)) < 1e-8
+    dv = np.sqrt(np.abs(np.einsum("bnkii->bnki", vo)).max(axis=(0, 1, 2)))
+    assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :] + 1e-300)) < 1e-6
