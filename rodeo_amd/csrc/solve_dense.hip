@@ -816,6 +816,8 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
     double* var = a.var + (size_t)b * (a.N + 1) * p * p;
     const double* Aode = a.theta;
     if (q_bd) load_qd(qd, a.Q, p, nd);
+    RK_STAMP_DECL(a.ws + a.ws_stride);
+    RK_STAMP_ZERO();
     // time 0: (ode_init, 0)   (solve.py:53-54, 114-121)
     for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
     for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
@@ -888,6 +890,7 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                     break;
             }
             if (run) wg_gemm(g);
+            RK_STAMP(ph);
         }
     }
 }

@@ -87,7 +87,12 @@ def c5(args):
     p, m = 160, 32
     F = (12 + 2 / 3) * p ** 3 + 4 * m * p * p + 4 * m * m * p + (2 / 3) * m ** 3
     ms = sum(prof.values())
-    if os.environ.get("RK_DENSE_STAMPS"):
+    if os.environ.get("RK_DENSE_STAMPS") == "fwd":
+        plan.filter(None); dev.sync()
+        ws = plan._ws.to_host().reshape(B, -1)
+        names = ["Q Sigma", "(Q Sigma) Q^T + R", "interrogation + W~ Sigma-", "S", "Sigma- W~^T", "LU + mean + downdate"]
+        print("fwd phase cycles per step (wg 0):", {k: int(v) for k, v in zip(names, ws[0, -2:-8:-1] / N)}, file=sys.stderr)
+    elif os.environ.get("RK_DENSE_STAMPS"):
         ws = plan._ws.to_host().reshape(B, -1)
         names = ["predict+T+diff", "LU panel", "LU swaps", "LU trsm", "LU gemm", "back trsm", "back gemm", "mean", "G D", "GDG^T"]
         cyc = ws[0, -2:-12:-1] / (N - 1)            # library built with -DRK_DENSE_STAMPS (solve_dense.hip)
