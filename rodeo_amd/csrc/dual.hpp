@@ -37,17 +37,66 @@ struct Dual {
         r.v = VEXPR;                                                                                      \
         _Pragma("unroll") for (int i = 0; i < P; ++i) r.d[i] = DEXPR;                                     \
         return r;                                                                                         \
-    }                                                                                                     \
-    template <int P>                                                                                      \
-    __device__ __forceinline__ Dual<P> operator OP(const Dual<P>& a, double b) { return a OP Dual<P>(b); } \
-    template <int P>                                                                                      \
-    __device__ __forceinline__ Dual<P> operator OP(double a, const Dual<P>& b) { return Dual<P>(a) OP b; }
+    }
 
 RK_DUAL_BIN(+, a.v + b.v, a.d[i] + b.d[i])
 RK_DUAL_BIN(-, a.v - b.v, a.d[i] - b.d[i])
 RK_DUAL_BIN(*, a.v * b.v, fma(a.d[i], b.v, a.v * b.d[i]))
 RK_DUAL_BIN(/, a.v / b.v, (a.d[i] - (a.v / b.v) * b.d[i]) / b.v)
 #undef RK_DUAL_BIN
+
+// a / b with a reciprocal and one correction (Markstein): q = a y, q + (a - b q) y with y = 1 / b.  Within an ulp of the
+// IEEE quotient (exact for most a, for all a when b = 3); y is a constant when b is, and loop-invariant when b is a
+// parameter -- three operations on the step's dependent chain instead of the eleven of a full division.
+__device__ __forceinline__ double div_by_scalar(double a, double b, double y) {
+    const double q = a * y;
+    return fma(fma(-b, q, a), y, q);
+}
+
+// Mixed operations with a plain double keep the structural zeros of the constant's derivative out of the arithmetic
+// (0 * x cannot be folded by the compiler under IEEE rules).
+template <int P>
+__device__ __forceinline__ Dual<P> operator+(const Dual<P>& a, double b) { Dual<P> r = a; r.v = a.v + b; return r; }
+template <int P>
+__device__ __forceinline__ Dual<P> operator+(double a, const Dual<P>& b) { Dual<P> r = b; r.v = a + b.v; return r; }
+template <int P>
+__device__ __forceinline__ Dual<P> operator-(const Dual<P>& a, double b) { Dual<P> r = a; r.v = a.v - b; return r; }
+template <int P>
+__device__ __forceinline__ Dual<P> operator-(double a, const Dual<P>& b) {
+    Dual<P> r;
+    r.v = a - b.v;
+#pragma unroll
+    for (int i = 0; i < P; ++i) r.d[i] = -b.d[i];
+    return r;
+}
+template <int P>
+__device__ __forceinline__ Dual<P> operator*(const Dual<P>& a, double b) {
+    Dual<P> r;
+    r.v = a.v * b;
+#pragma unroll
+    for (int i = 0; i < P; ++i) r.d[i] = a.d[i] * b;
+    return r;
+}
+template <int P>
+__device__ __forceinline__ Dual<P> operator*(double a, const Dual<P>& b) { return b * a; }
+template <int P>
+__device__ __forceinline__ Dual<P> operator/(const Dual<P>& a, double b) {
+    const double y = 1.0 / b;
+    Dual<P> r;
+    r.v = div_by_scalar(a.v, b, y);
+#pragma unroll
+    for (int i = 0; i < P; ++i) r.d[i] = div_by_scalar(a.d[i], b, y);
+    return r;
+}
+template <int P>
+__device__ __forceinline__ Dual<P> operator/(double a, const Dual<P>& b) {
+    Dual<P> r;
+    r.v = a / b.v;
+    const double f = -r.v / b.v;
+#pragma unroll
+    for (int i = 0; i < P; ++i) r.d[i] = f * b.d[i];
+    return r;
+}
 
 template <int P>
 __device__ __forceinline__ Dual<P> operator-(const Dual<P>& a) {
