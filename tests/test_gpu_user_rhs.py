@@ -241,3 +241,13 @@ def test_six_block_user_ode_multi_wave_tile_path(ra):
     xo = scan.solve_sim(4, o_ode, W, x0, 0., 6., N, functools.partial(oi.interrogate_chkrebtii, kalman_type="standard"),
                         prior, theta=theta)
     assert np.max(np.abs(x - xo)) < 1e-6
+
+
+def test_readme_quick_start_example():
+    """examples/readme_fitzhugh.py: the reference README's quick start, call for call, with the ODE given as source."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "readme_fitzhugh.py")
+    spec = importlib.util.spec_from_file_location("readme_fitzhugh", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() < 5e-3                      # dt = 0.05: the solver's own discretisation error against odeint
