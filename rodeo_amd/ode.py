@@ -11,7 +11,8 @@ exist as device code: a ``DeviceODE`` couples
                        preparation only (``first_order_pad(...)[1]``, src/rodeo/utils.py:96-98),
   * ``param_spec``  -- how ``**params`` are packed into the per-trajectory parameter vector ``theta``.
 
-Passing a plain Python callable to ``solve_mv`` / ``solve_sim`` raises ``TypeError`` -- there is no CPU fallback.
+A plain Python callable (written with NumPy like the reference's JAX functions) is TRACED into such device code:
+``from_python`` below / automatically inside ``solve_mv`` / ``solve_sim`` (rodeo_amd/trace.py).  There is no CPU fallback.
 """
 import numpy as np
 from . import _lib
@@ -136,6 +137,12 @@ def from_source(type_name, source, n_block, param_spec=(), host_fun=None, name=N
         raise TypeError(f"ODE '{name or type_name}' was registered without a host_fun; it cannot be evaluated on the host")
 
     return DeviceODE(name or type_name, rid.value, int(n_block), 1, param_spec, host_fun or _no_host)
+
+
+def from_python(fun, n_vars, n_deriv_used=2, name=None, **param_sizes):
+    """``DeviceODE`` from an ordinary Python ``fun(X, t, **params)``; see rodeo_amd/trace.py."""
+    from .trace import from_python as _fp
+    return _fp(fun, n_vars, n_deriv_used, name, **param_sizes)
 
 
 def compile_check(ode, n_bstate, interrogate_id=_lib.INTERROGATE_KRAMER):

@@ -13,7 +13,8 @@ inside fused HIP kernels (rodeo_amd/csrc/solve_small.hip); nothing is computed o
 fallback.
 
 Differences from the reference that a caller can see:
-  * ``ode_fun`` must be a ``rodeo_amd.ode.DeviceODE`` (device code for the right-hand side), and ``interrogate`` one
+  * ``ode_fun`` is a ``rodeo_amd.ode.DeviceODE`` (device code for the right-hand side) or an ordinary Python function,
+    which is traced into device code on first use (``rodeo_amd/trace.py``), and ``interrogate`` one
     of the four functions of ``rodeo_amd.interrogate`` (recognised by identity, ``functools.partial`` allowed);
   * ``key`` is an integer seed (or ``None``) for a Philox counter stream instead of a JAX threefry key -- draws have
     the reference's law, not its bit-stream ("parity unpinned" for draws).
@@ -67,8 +68,15 @@ class SolvePlan:
         if kalman_type not in _KALMAN:
             raise NotImplementedError                    # src/rodeo/solve.py:142-143, 240-241
         if not isinstance(ode_fun, DeviceODE):
-            raise TypeError("ode_fun must be a rodeo_amd.ode.DeviceODE: the time loop runs on the GPU and needs device "
-                            "code for the right-hand side (see rodeo_amd/ode.py); there is no CPU fallback")
+            if not callable(ode_fun):
+                raise TypeError("ode_fun must be a rodeo_amd.ode.DeviceODE or a traceable Python function: the time loop "
+                                "runs on the GPU and needs device code for the right-hand side (see rodeo_amd/ode.py); "
+                                "there is no CPU fallback")
+            # an ordinary Python right-hand side, like the reference's: traced once into device code (rodeo_amd/trace.py)
+            from .trace import from_python
+            skip = {"kalman_type"}
+            sizes = {k: int(np.shape(v)[-1]) if np.ndim(v) >= 1 else 1 for k, v in params.items() if k not in skip}
+            ode_fun = from_python(ode_fun, int(np.shape(ode_weight)[-3]), min(2, int(np.shape(ode_weight)[-1])), **sizes)
         self.dev = device if device is not None else default_device()
         self._ode_fun = ode_fun
         itg_id, bound = _interrogate_id(interrogate)

@@ -244,10 +244,35 @@ def test_six_block_user_ode_multi_wave_tile_path(ra):
 
 
 def test_readme_quick_start_example():
-    """examples/readme_fitzhugh.py: the reference README's quick start, call for call, with the ODE given as source."""
+    """examples/readme_fitzhugh.py: the reference README's quick start, call for call, with its plain Python ode_fun
+    (traced into device code, rodeo_amd/trace.py)."""
     import importlib.util, os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "readme_fitzhugh.py")
     spec = importlib.util.spec_from_file_location("readme_fitzhugh", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main() < 5e-3                      # dt = 0.05: the solver's own discretisation error against odeint
+
+
+def test_traced_python_rhs_batched_lorenz(ra):
+    """A Python right-hand side with three blocks, traced (ode.from_python), batched, p = 3 and 4, against the oracle."""
+    def lorenz(X, t, **params):
+        rho, sigma, beta = params["theta"]
+        x, y, z = X[:, 0]
+        return np.array([[-sigma * x + sigma * y], [rho * x - y - x * z], [-beta * z + x * y]])
+    dev = ra.ode.from_python(lorenz, 3, theta=3)
+    B, N = 5, 60
+    rng = np.random.default_rng(3)
+    theta = np.array([28., 10., 8. / 3.]) * np.exp(0.01 * rng.standard_normal((B, 3)))
+    for p in (3, 4):
+        W, init = ra.utils.first_order_pad(dev, 3, p)
+        x0 = init(np.array([-12., -5., 38.]) + 0.1 * rng.standard_normal((B, 3)), 0.0, theta=theta)
+        prior = ra.ibm_init(1e-3, p, np.array([5e7] * 3))
+        for name in ("kramer", "rodeo"):
+            g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+            m, v = ra.solve_mv(None, dev, W, x0, 0., N * 1e-3, N, g, prior, theta=theta)
+            mo, vo = scan.solve_mv(None, odes.lorenz63, W, x0, 0., N * 1e-3, N, o, prior, theta=theta)
+            sm = np.max(np.abs(mo), axis=(0, 1, 2))
+            assert np.max(np.abs(m - mo) / sm) < 1e-8
+    with pytest.raises(TypeError):                                   # data-dependent control flow cannot be traced
+        ra.ode.from_python(lambda X, t: np.array([[X[0, 0] if X[0, 0] > 0 else -X[0, 0]]]), 1)

@@ -69,3 +69,31 @@ def test_user_sources_compile_for_gfx950_without_gpu():
     assert "Broken" in str(e.value) or "error" in str(e.value)
     with pytest.raises(TypeError):
         fn(np.zeros((2, 3)), 0.0, theta=np.ones(3))          # registered without a host twin
+
+
+def test_trace_python_rhs_to_source_and_compile():
+    """ode.from_python: the generated struct, NDEP detection, powers / elementary functions, host twin, hiprtc build."""
+    import rodeo_amd as ra
+    from rodeo_amd import trace
+
+    def fitz_fun(X, t, **params):
+        a, b, c = params["theta"]
+        V, R = X[:, 0]
+        return np.array([[c * (V - V * V * V / 3 + R)], [-1 / c * (V - a + b * R)]])
+    src, ndep = trace.trace_source(fitz_fun, 2, 2, (("theta", 3),), "Probe")
+    assert ndep == 1 and "static constexpr int D = 2;" in src and "NTHETA = 3" in src
+    assert "out[0] = (th[2] * ((X[0][0] - (((X[0][0] * X[0][0]) * X[0][0]) / 3.0)) + X[1][0]));" in src
+
+    def second(X, t, k):
+        return np.array([[np.sin(2 * t) - k[0] * X[0, 0] - 0.1 * X[0, 1] ** 3 + np.exp(-X[0, 0] ** 2) + np.sqrt(1.0 + X[0, 0] ** 2)]])
+    src2, ndep2 = trace.trace_source(second, 1, 2, (("k", 1),), "Probe2")
+    assert ndep2 == 2 and "sin((2.0 * t))" in src2 and "exp(" in src2 and "sqrt(" in src2
+    ode = ra.ode.from_python(fitz_fun, 2, theta=3)
+    assert ra.ode.from_python(fitz_fun, 2, theta=3) is ode                    # cached
+    ra.ode.compile_check(ode, 3)
+    ra.ode.compile_check(ra.ode.from_python(second, 1, k=1), 4)
+    X = np.array([[-1., 0, 0], [1., 0, 0]])
+    np.testing.assert_allclose(ode(X, 0.0, theta=np.array([.2, .2, 3.])).ravel(), [1.0, 1.0 / 3.0], rtol=1e-15)
+    assert ode(np.zeros((4, 2, 3)), 0.0, theta=np.ones((4, 3))).shape == (4, 2, 1)
+    with pytest.raises(TypeError):
+        trace.trace_source(lambda X, t: np.array([[abs(X[0, 0]) if X[0, 0] > 0 else 0.0]]), 1, 2, (), "Bad")
