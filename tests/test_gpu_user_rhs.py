@@ -276,3 +276,59 @@ def test_traced_python_rhs_batched_lorenz(ra):
             assert np.max(np.abs(m - mo) / sm) < 1e-8
     with pytest.raises(TypeError):                                   # data-dependent control flow cannot be traced
         ra.ode.from_python(lambda X, t: np.array([[X[0, 0] if X[0, 0] > 0 else -X[0, 0]]]), 1)
+
+
+def _oracle_ode(name, fun, d):
+    """Oracle ODE from the same Python function: block Jacobian by complex-step differentiation."""
+    def f(X, t, **params):
+        X = np.asarray(X)
+        if X.ndim == 2:
+            return np.asarray(fun(X, t, **params))
+        lead = X.shape[:-2]
+        out = np.empty(lead + (d, 1), dtype=X.dtype)
+        for idx in np.ndindex(*lead):
+            out[idx] = np.asarray(fun(X[idx], t, **{k: (np.asarray(v)[idx] if np.ndim(v) >= 2 else v) for k, v in params.items()}))
+        return out
+    o = odes.ODE(name, d, 1, f, None)
+    o._jac = lambda X, t, **params: odes.complex_step_blockjac(o, X, t, **params)
+    return o
+
+
+@pytest.mark.parametrize("name", ["kramer", "schober"])
+def test_traced_reference_example_odes(ra, name):
+    """The reference's other example systems (examples/timings.py:271-278 Hes1 on the log scale, :368-381 SEIRAH with six
+    variables), as plain Python, traced and solved on the device against the oracle running the same functions."""
+    def hes1(X, t, **params):
+        P, M, H = np.exp(X[:, 0])
+        a, b, c, d, e, f, g = params["theta"]
+        logP = -a * H + b * M / P - c
+        logM = -d + e / (1 + P * P) / M
+        logH = -a * P + f / (1 + P * P) / H - g
+        return np.array([[logP], [logM], [logH]])
+
+    def seirah(X, t, **params):
+        S, E, I, R, A, H = X[:, 0]
+        N = S + E + I + R + A + H
+        b, r, alpha, D_e, D_I, D_q = params["theta"]
+        D_h = 30
+        dS = -b * S * (I + alpha * A) / N
+        dE = b * S * (I + alpha * A) / N - E / D_e
+        dI = r * E / D_e - I / D_q - I / D_I
+        dR = (I + A) / D_I + H / D_h
+        dA = (1 - r) * E / D_e - A / D_I
+        dH = I / D_q - H / D_h
+        return np.array([[dS], [dE], [dI], [dR], [dA], [dH]])
+
+    g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+    cases = [(hes1, 3, np.log([1.439, 2.037, 17.904]), np.array([0.022, 0.3, 0.031, 0.028, 0.5, 20, 0.3]), 30.0, 120),
+             (seirah, 6, np.array([63884630., 15492., 21752., 0., 618013., 13388.]),
+              np.array([2.23, 0.034, 0.55, 5.1, 2.3, 1.13]), 6.0, 60)]
+    for fun, d, x0v, theta, t_max, N in cases:
+        W, init = ra.utils.first_order_pad(fun, d, 3)
+        x0 = init(x0v, 0.0, theta=theta)
+        prior = ra.ibm_init(t_max / N, 3, np.array([.1] * d))
+        m, v = ra.solve_mv(None, fun, W, x0, 0.0, t_max, N, g, prior, theta=theta)       # the Python function itself
+        mo, vo = scan.solve_mv(None, _oracle_ode(fun.__name__, fun, d), W, x0, 0.0, t_max, N, o, prior, theta=theta)
+        sm = np.max(np.abs(mo), axis=(0, 1))
+        assert np.all(np.isfinite(mo)) and np.max(np.abs(m - mo) / np.maximum(sm, 1e-300)) < 1e-8
+        assert np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))
