@@ -84,7 +84,9 @@ def test_errors(ra):
     with pytest.raises(NotImplementedError):                                  # solve.py:142-143
         ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"],
                     kalman_type="nope", theta=s["theta"])
-    with pytest.raises(TypeError):
+    with pytest.raises(TypeError):                                            # neither device code nor a function
+        ra.solve_mv(None, "fitz", *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
+    with pytest.raises(ValueError):                                           # a Python function is traced: wrong output shape
         ra.solve_mv(None, lambda X, t, **p: X, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
     with pytest.raises(TypeError):
         ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, lambda **k: None, s["prior"], theta=s["theta"])
