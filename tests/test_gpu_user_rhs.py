@@ -332,3 +332,25 @@ def test_traced_reference_example_odes(ra, name):
         sm = np.max(np.abs(mo), axis=(0, 1))
         assert np.all(np.isfinite(mo)) and np.max(np.abs(m - mo) / np.maximum(sm, 1e-300)) < 1e-8
         assert np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))
+
+
+def test_traced_higher_order_example(ra):
+    """docs/examples/higher_order.md:47-86 with its Python ode_fun: x'' = sin(2t) - x as a 4-state block with the custom
+    weight W = [[[0, 0, 1, 0]]]; solve_mv against the analytic solution (K4) and the built-in functor, solve_sim +
+    interrogate_chkrebtii (the example's sampler) against the oracle on the shared stream."""
+    def higher_fun(x, t, **params):
+        return np.array([[np.sin(2 * t) - x[0, 0]]])
+    W = np.array([[[0., 0., 1., 0.]]])
+    x0 = np.array([[-1., 0., 1., 0.]])
+    N, t_max = 200, 10.0
+    prior = ra.ibm_init(t_max / N, 4, np.array([.001]))
+    m, _ = ra.solve_mv(None, higher_fun, W, x0, 0., t_max, N, ra.interrogate.interrogate_kramer, prior)
+    mb, _ = ra.solve_mv(None, ra.ode.higher_order, W, x0, 0., t_max, N, ra.interrogate.interrogate_kramer, prior)
+    t = np.linspace(0, t_max, N + 1)
+    exact = (2 * np.sin(t) - 3 * np.cos(t) - np.sin(2 * t)) / 3
+    assert np.max(np.abs(m[:, 0, 0] - exact)) < 2e-3 and np.max(np.abs(m - mb)) < 1e-10
+    g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="standard")
+    o = functools.partial(oi.interrogate_chkrebtii, kalman_type="standard")
+    x = ra.solve_sim(11, higher_fun, W, x0, 0., t_max, N, g, prior)
+    xo = scan.solve_sim(11, odes.higher_order, W, x0, 0., t_max, N, o, prior)
+    assert x.shape == (N + 1, 1, 4) and np.max(np.abs(x - xo)) < 1e-7
