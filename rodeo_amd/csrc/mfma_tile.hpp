@@ -43,12 +43,8 @@ __device__ __forceinline__ double dpp64_banks(double old, double x) {
 __device__ __forceinline__ double pair_block0(double x) { return dpp64_banks<0x124, 0xA>(x, x); }   // odd g <- g-1
 __device__ __forceinline__ double pair_block1(double x) { return dpp64_banks<0x12C, 0x5>(x, x); }   // even g <- g+1
 
-// value of the OTHER block of this lane's trajectory (n_block = 2)
-__device__ __forceinline__ double pair_other(double x) {
-    return dpp64_banks<0x124, 0xA>(dpp64_banks<0x12C, 0x5>(x, x), x);
-}
-
-// pair_other for a value that is already the same in the four lanes of every (r, g) quad: row_half_mirror reverses each
+// Value of the OTHER block of this lane's trajectory (n_block = 2) for a value that is already the same in the four
+// lanes of every (r, g) quad: row_half_mirror reverses each
 // 8-lane half of a DPP row, lane (g, c) <- (g ^ 1, 3 - c), one move per 32-bit half instead of two moves + a copy
 __device__ __forceinline__ double pair_other_quad_uniform(double x) {
     const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x141, 0xf, 0xf, false);   // no `old`: every lane has a source
@@ -150,23 +146,5 @@ __device__ __forceinline__ void lds_dma_wait_all() {
     asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// One 8-byte store per lane of `mask` at row + voff, with the row pointer in SGPRs: a per-lane 64-bit pointer would
-// cost a VALU add per store (moving it from row to row), and VALU work does not hide in the gaps of a dependent MFMA
-// chain (profiles/r01_probe3_mfma_valu_serialize.log).  EXEC must be all ones on entry (whole-wave code only).
-// hipcc does not see inside the statement, so the wait states an MFMA result needs before a VMEM instruction may read
-// it (9 for the 4-pass f64 MFMA: hipcc itself emits s_nop 8 there) are the caller's business:
-//   store_f64_masked_after: `after` is a VALU result computed from v, which orders the store behind that instruction
-//                           (>= 9 cycles with the s_nop 4 hipcc puts before the VALU read, the VALU op and s_nop 0);
-//   store_f64_masked_mfma : v comes straight from an MFMA, the statement opens with s_nop 8.
-__device__ __forceinline__ void store_f64_masked_after(const void* row /* wave-uniform */, unsigned voff, double v,
-                                                       unsigned long long mask /* wave-uniform */, double after) {
-    asm volatile("s_nop 0\n\ts_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1"
-                 :: "v"(voff), "v"(v), "s"(row), "s"(mask), "v"(after) : "memory");
-}
-__device__ __forceinline__ void store_f64_masked_mfma(const void* row, unsigned voff, double v, unsigned long long mask) {
-    asm volatile("s_nop 8\n\ts_mov_b64 exec, %3\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_mov_b64 exec, -1"
-                 :: "v"(voff), "v"(v), "s"(row), "s"(mask) : "memory");
-}
 
 }  // namespace rk
