@@ -188,9 +188,11 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
                          int32_t n_obs, double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
                          double* logpost);
 
-/* Fenrir's backward pass (src/rodeo/inference/fenrir.py:86-259; the forward pass is rk_solve_filter with
- * RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR, fenrir.py:304-313): log p(y_{0:M} | Z_{1:N}) per trajectory from the
- * stored filtered and predicted moments in `out` (same cfg / in as the filter call).  Observations are scalar per
+/* Fenrir's backward pass (src/rodeo/inference/fenrir.py:86-259; the forward pass is rk_solve_filter with the same
+ * cfg / in, fenrir.py:304-313): log p(y_{0:M} | Z_{1:N}) per trajectory from the filter's output in `out` -- either
+ * the RK_LAYOUT_TILE3 tiles (no flags; predicted moments are re-evaluated on the fly) when rk_solve_layout reports that
+ * layout for RK_MODE_FILTER, or the batch-minor filtered and predicted moments of a call with
+ * RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR.  Observations are scalar per
  * block (n_bobs = 1): obs (n_obs, d), obs_weight (n_obs, d, p), obs_var (n_obs, d) row-major on device, shared by all
  * trajectories; obs_ind (n_obs) = searchsorted(sim_times, obs_times), ascending.  logdens (B) is overwritten.
  * The log-density follows src/rodeo/utils.py:60-78 (a forecast variance with |w| <= 1e-8 contributes nothing).      */

@@ -393,6 +393,8 @@ size_t tile4_doubles(const rk_solve_cfg* c);
 // MFMA-tile path (solve_tile3.hip)
 bool tile3_supported(const rk_solve_cfg* c, int mode);
 int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
+int tile3_fenrir_backward(rk_handle h, const SolveArgs& a, const double* tiles, const double* obs, const double* obs_w,
+                          const double* obs_v, const int32_t* obs_ind, int n_obs, double* logdens);
 
 }  // namespace rk
 
@@ -541,10 +543,21 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
                        int32_t n_obs, double* logdens) {
     RK_REQUIRE(h && c && in && out && obs && obs_weight && obs_var && obs_ind && logdens, RK_ERR_INVALID,
                "rk_fenrir_backward: null argument");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_backward: kalman_type must be standard");
+    if (!(c->flags & (RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)) && tile3_supported(c, RK_MODE_FILTER)) {
+        // the filter ran on the MFMA-tile path: out->var_state holds the RK_LAYOUT_TILE3 tiles, predicted moments are
+        // re-evaluated from the filtered ones (solve_tile3.hip, fenrir_bwd_tile3_kernel)
+        RK_REQUIRE(out->var_state && n_obs >= 0, RK_ERR_INVALID, "rk_fenrir_backward: out->var_state (tiles) is null");
+        SolveArgs at;
+        int rct = make_args(c, in, out, at);
+        if (rct) return rct;
+        RK_HIP(hipSetDevice(h->device));
+        RK_HIP(hipMemsetAsync(logdens, 0, sizeof(double) * (size_t)c->n_traj, h->stream));
+        return tile3_fenrir_backward(h, at, out->var_state, obs, obs_weight, obs_var, obs_ind, n_obs, logdens);
+    }
     RK_REQUIRE(out->mean_state && out->var_state && out->mean_pred && out->var_pred, RK_ERR_INVALID,
                "rk_fenrir_backward needs the batch-minor filtered AND predicted moments of rk_solve_filter "
-               "(RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)");
-    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_backward: kalman_type must be standard");
+               "(RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR), or a configuration of the tile path (n_bstate = 3) without them");
     RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6 && n_obs >= 0, RK_ERR_UNSUPPORTED,
                "rk_fenrir_backward: n_bstate in 2..6, scalar observations per block");
     SolveArgs a;

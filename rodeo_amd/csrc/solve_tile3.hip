@@ -248,6 +248,226 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
     }
 }
 
+// ---- Fenrir backward pass on the tile path (src/rodeo/inference/fenrir.py:86-259) -------------------------------------
+// The backward Markov chain of smooth_cond maps (A = G, b = mu_f - G mu-, C = Sigma_f - G T^T, standard.py:366-370) run
+// as a Kalman filter backwards in time IS the carry recursion of smooth_mv started from filt[N]:
+//     A M A^T + C = G M G^T + (Sigma_f - G Sigma- G^T)      (T^T = Sigma- G^T),
+// interrupted by an observation update wherever an observation sits on the grid.  So the kernel is bwd_mv_tile3_kernel
+// with the same producers, a consumer that stores nothing, conditions on the observations (rare: a slow per-step path
+// for the chunks that contain one) and accumulates their log-densities.  Predicted moments are re-evaluated from the
+// filtered ones like everywhere on the tile path, so the forward pass is the MFMA-tile forward kernel.
+struct FenrirObs {
+    const double *obs, *obs_w, *obs_v;      // (n_obs, D), (n_obs, D, 3), (n_obs, D)
+    const int32_t* obs_ind;                 // (n_obs,) ascending grid indices
+    int n_obs;
+    double* logdens;                        // (B,), zeroed by the caller
+};
+
+__global__ void __launch_bounds__(256) fenrir_bwd_tile3_kernel(SolveArgs a, const double* __restrict__ tiles, int D, FenrirObs ob) {
+    constexpr int P = 3;
+    __shared__ __attribute__((aligned(16))) char lds_all[2 * BUF_BYTES];
+    __shared__ __attribute__((aligned(16))) char zones[3 * ZONE_BYTES];      // the producers' prefetch landing zones
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;    // 0 = consumer; producers q = wave - 1 own ch = q (mod 3)
+    const int n_tiles = a.B * D;
+    const size_t tstride = (size_t)n_tiles * TILE_DOUBLES;
+    const int n_chunks = (a.N - 1 + CHUNK - 1) / CHUNK;            // steps n = N-1 .. 1
+
+    // constant entries of the hand-off tiles (row 3 = e_3; column 3 of G~^T = e_3) are written once
+    for (int i = threadIdx.x; i < 2 * 64 * 3 * 16; i += 256) {
+        const int idx = i & 15, which = (i >> 4) % 3, item = ((i >> 4) / 3) & 63, buf = i / (64 * 3 * 16);
+        const double v = (idx == 15) ? 1.0 : 0.0;
+        *(double*)(lds_all + buf * BUF_BYTES + lds_byte(item >> 2, item & 3, which, idx)) = v;
+    }
+    __syncthreads();
+
+    const int tw = blockIdx.x;                                     // tile-wave index: tiles 4 tw .. 4 tw + 3
+    char* const lds_raw = lds_all;
+
+    if (wave >= 1) {
+        // ---------------- producers: one lane per (step-in-chunk, tile) ----------------
+        const int p = wave - 1;
+        const int s = lane >> 2, g = lane & 3;
+        int tau = tw * 4 + g;
+        if (tau >= n_tiles) tau = n_tiles - 1;
+        const int b = tau / D, blk = tau - b * D;
+        double Q[P][P], R[P][P];
+        load_block_consts<P>(a, blk, b, Q, R);
+        int woff[12];                                              // LDS byte offsets of the 12 slots this lane writes
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) woff[i * 4 + j] = lds_byte(s, g, 0, i * 4 + j);
+        // The filt tiles of this producer's next chunk are prefetched by LDS-DMA into the wave's own 6 KiB landing zone
+        // right after stage 1 has read the zone, three ticks before they are needed; no prefetch lives in registers
+        // (mfma_tile.hpp, lds_dma16).  The zone is the image of the chunk's 16 rows x 384 contiguous bytes (this
+        // tile-wave's 4 tiles in 16 time rows): piece j = 64 i + lane of instruction i is bytes 16 (j % 24) of row
+        // j / 24, so one instruction reads 2 2/3 whole rows (measured: 64 scattered 16-byte pieces per instruction
+        // cost 185-280 cycles of issue each, whole rows about a quarter of that).
+        char* const zone = zones + p * ZONE_BYTES;
+        const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
+        int frow[6], fcol[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const int j = 64 * i + lane; frow[i] = j / 24; fcol[i] = (j % 24) * 16; }
+        const char* const wave_tiles = (const char*)(tiles + (size_t)tw * 4 * TILE_DOUBLES);
+        auto fetch = [&](int ch) {
+            const int n_hi = a.N - 1 - ch * CHUNK;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int n = n_hi - frow[i];                        // rows past the start (n < 1) are clamped, never handed over
+                lds_dma16(wave_tiles + (size_t)(n < 1 ? 1 : n) * tstride * 8 + fcol[i], zone_lds + 1024 * i);
+            }
+        };
+        lds_dma_wait_all();                                        // retire the loads of Q, R before the first DMA
+        if (p < n_chunks) fetch(p);
+        // Chunk ch passes through three stages in the ticks ch-3, ch-2, ch-1 (one workgroup barrier per tick), so in
+        // every tick the three producers each run a different stage of three different chunks: equal work per SIMD
+        // and tick.  All state between stages stays in this wave's registers.
+        double mf[P], Sf[P][P], mp[P], Sp[P][P], A[P][P], X[P][P], rpiv[P];
+        for (int t = -3; t < n_chunks; ++t) {
+            const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
+            if (ch1 % 3 == p) {
+                // ---- stage 1 of chunk ch1: take the fetched tiles, start the next fetch, predict ----
+                if (ch1 < n_chunks) {
+                    lds_dma_wait_all();
+                    double buf[TILE_DOUBLES];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const double2 v = *(const double2*)(zone + 96 * lane + 16 * k);      // lane = 4 s + g
+                        buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
+                    }
+                    lds_reads_done();
+                    if (ch1 + 3 < n_chunks) fetch(ch1 + 3);
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+#pragma unroll
+                        for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
+                        mf[i] = buf[i * 4 + 3];
+                    }
+                    predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
+                }
+            } else if (ch2 >= 0 && ch2 % 3 == p) {
+                // ---- stage 2 of chunk ch2: T^T = (Sigma_f Q^T)^T (standard.py:175), LU of Sigma-, forward sweep ----
+                if (ch2 < n_chunks) {
+                    double T[P][P];
+                    mm_nt<P, P, P>(Sf, Q, T);
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
+                    lu_factor_fwd<P, P>(A, X, rpiv);
+                }
+            } else if (ch3 >= 0) {
+                // ---- stage 3 of chunk ch3: back substitution, X = solve(Sigma-, T^T) = G^T (standard.py:176), hand-off ----
+                if (ch3 < n_chunks) {
+                    lu_back<P, P>(A, X, rpiv);
+                    const int n = a.N - 1 - ch3 * CHUNK - s;
+                    if (n >= 1) {
+                        char* o = lds_raw + (ch3 & 1) * BUF_BYTES;
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+#pragma unroll
+                            for (int j = 0; j < P; ++j) {
+                                *(double*)(o + woff[i * 4 + j]) = Sp[i][j];             // M-   (which = 0)
+                                *(double*)(o + woff[i * 4 + j] + 128) = X[i][j];        // G~^T (which = 1)
+                                *(double*)(o + woff[i * 4 + j] + 256) = Sf[i][j];       // M_f  (which = 2)
+                            }
+                            *(double*)(o + woff[i * 4 + 3]) = mp[i];
+                            *(double*)(o + woff[i * 4 + 3] + 256) = mf[i];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---------------- consumer: the backward filter on MFMA tiles ----------------
+        __builtin_amdgcn_s_setprio(3);
+        const int r = lane >> 4, g = (lane >> 2) & 3, c = lane & 3, idx = r * 4 + c;
+        const int tau_raw = tw * 4 + g;
+        const bool valid = tau_raw < n_tiles;
+        const int tau = valid ? tau_raw : n_tiles - 1;
+        const int b = tau / D, blk = tau - b * D;
+        const bool in_tile = valid && r < 3;
+        const double e3 = (r == 3 && c == 3) ? 1.0 : 0.0, I4 = r == c ? 1.0 : 0.0;
+        const double* const my = tiles + (size_t)tau * TILE_DOUBLES + idx;
+        int roff[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) roff[k] = lds_byte(k, g, 0, idx) - k * 4 * ITEM_BYTES;
+        double Ms = in_tile ? my[(size_t)a.N * tstride] : e3;       // terminal point filt[N]   (fenrir.py:186-188)
+        double acc = 0.0;
+        int i = ob.n_obs - 1;
+        int next = i >= 0 ? ob.obs_ind[i] : -1;                     // grid index of the next observation (backwards in time)
+        // Conditioning on observation i (forecast standard.py:333-335, log-density, update standard.py:93-102) is the
+        // forward update in tile form with the measurement row X_w = [D_0, D_1, D_2 | -y] and var_meas = Omega:
+        //     WS = MF(X_w, M) = [D Sigma | D mu - y] ; Z = MF(M^T with row 3 zeroed, X_w) = Sigma D^T ; w = MF(Z, X_w) + Omega
+        // (the transpose is one MFMA with the identity).  Observations are rare, so this path is not tuned.
+        auto observe = [&]() {
+            const double xw = valid ? (r < 3 ? ob.obs_w[((size_t)i * D + blk) * 3 + r] : -ob.obs[(size_t)i * D + blk]) : 0.0;
+            const double Om = valid ? ob.obs_v[(size_t)i * D + blk] : 1.0;
+            double MsT = MF(Ms, I4, 0.0);
+            MsT = r == 3 ? 0.0 : MsT;
+            const double WS = MF(xw, Ms, 0.0);
+            const double Z = MF(MsT, xw, 0.0);
+            const double w = MF(Z, xw, 0.0) + Om;                               // var_fore
+            const double z = -quad_bcast3(WS);                                  // y - D mu
+            if (fabs(w) > 1e-8) acc += -0.5 * (z * z / w + log(w)) - 0.5 * 1.83787706640934548356;   // utils.py:60-78
+            const double K = Z / w;                                             // solve_var with a 1 x 1 system
+            Ms = fma(-K, WS, Ms);
+            --i;
+            next = i >= 0 ? ob.obs_ind[i] : -1;
+        };
+        if (next >= a.N) observe();                                 // fenrir.py:189-209
+        __syncthreads();                                            // tick -3
+        __syncthreads();                                            // tick -2
+        __syncthreads();                                            // tick -1: chunk 0 is in LDS
+        for (int t = 0; t < n_chunks; ++t) {
+            const char* in = lds_raw + (t & 1) * BUF_BYTES;
+            const int n_hi = a.N - 1 - t * CHUNK;
+            const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CHUNK ? CHUNK : n_hi);   // steps n_hi .. n_hi-cnt+1
+            const bool has_obs = next > n_hi - cnt;
+            if (cnt == CHUNK && !has_obs) {
+                // the 16-step dependent chain of bwd_mv_tile3_kernel, nothing stored:
+                //     D = M - M- ; V = MF(D, G~^T) ; M = MF(V, G~^T, M_f)   = G M G^T + (M_f - G M- G^T)  (standard.py:366-370)
+                constexpr int LOOKAHEAD = 4;
+                double Mp[CHUNK], Gt[CHUNK], Mf[CHUNK];
+                auto load = [&](int s) {
+                    const char* q = in + roff[s & 3] + s * 4 * ITEM_BYTES;
+                    Mp[s] = *(const double*)(q);
+                    Gt[s] = *(const double*)(q + 128);
+                    Mf[s] = *(const double*)(q + 256);
+                };
+#pragma unroll
+                for (int s = 0; s < LOOKAHEAD; ++s) load(s);
+                double Dm = Ms - Mp[0];
+#pragma unroll
+                for (int s = 0; s < CHUNK; ++s) {
+                    if (s + LOOKAHEAD < CHUNK) load(s + LOOKAHEAD);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double V1 = MF(Dm, Gt[s], 0.0);
+                    Ms = MF(V1, Gt[s], Mf[s]);
+                    if (s + 1 < CHUNK) Dm = Ms - Mp[s + 1];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (int s = 0; s < cnt; ++s) {
+                    const char* q = in + lds_byte(s, g, 0, idx);
+                    const double Mp = *(const double*)(q), Gt = *(const double*)(q + 128), Mf = *(const double*)(q + 256);
+                    const double V1 = MF(Ms - Mp, Gt, 0.0);
+                    Ms = MF(V1, Gt, Mf);
+                    if (next == n_hi - s) observe();                            // fenrir.py:155-170
+                }
+            }
+            __syncthreads();
+        }
+        // n = 0: filt[0] = (ode_init, 0) has G = 0, so the state there is filt[0] itself whatever came before
+        if (next == 0) {
+            Ms = in_tile ? my[0] : e3;
+            observe();
+        }
+        if (valid && r == 0 && c == 0) atomicAdd(&ob.logdens[b], acc);
+    }
+}
+
 // ---- backward sampler (solve.py:162-204): x_n = mu_f + G (x_{n+1} - mu-) + L~ z_n --------------------------------
 // Everything but the chain in x is carry-independent, so the producers (same three-stage scheme as above) evaluate per
 // (step, tile): G, mu-, and mu_f + L~ z with L~ = psd_factor(Sigma_f - G T^T) (standard.py:248-254, the draw of
@@ -492,6 +712,18 @@ int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     if (a.N < 2) return rc;
     LaunchTimer t(h, "bwd_mv_tile3_kernel");
     hipLaunchKernelGGL(bwd_mv_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(256), 0, h->stream, a, tiles, a.D);
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+// rk_fenrir_backward on the tile layout: `tiles` = the filtered moments of rk_solve_filter in RK_LAYOUT_TILE3
+int tile3_fenrir_backward(rk_handle h, const SolveArgs& a, const double* tiles, const double* obs, const double* obs_w,
+                          const double* obs_v, const int32_t* obs_ind, int n_obs, double* logdens) {
+    FenrirObs ob;
+    ob.obs = obs; ob.obs_w = obs_w; ob.obs_v = obs_v; ob.obs_ind = obs_ind; ob.n_obs = n_obs; ob.logdens = logdens;
+    LaunchTimer t(h, "fenrir_bwd_tile3_kernel");
+    hipLaunchKernelGGL(fenrir_bwd_tile3_kernel, dim3(div_up(a.B * a.D, 4)), dim3(256), 0, h->stream, a, tiles, a.D, ob);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

@@ -2,8 +2,9 @@
 ``rodeo.inference.fenrir`` (src/rodeo/inference/fenrir.py:261-327): the Fenrir approximate log-likelihood
 log p(Y_{0:M} | Z_{1:N}) -- forward filter (``_solve_filter``, storing the predicted moments), then the backward
 Markov chain of ``smooth_cond`` run as a Kalman filter backwards in time that conditions on the observations
-(``_backward``, fenrir.py:86-259).  Both passes run on the device (``rk_solve_filter`` with
-``RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR`` + ``rk_fenrir_backward``); only B doubles come back.
+(``_backward``, fenrir.py:86-259).  Both passes run on the device (``rk_solve_filter`` + ``rk_fenrir_backward``: on
+the MFMA-tile kernels at n_bstate = 3, else lane-per-trajectory with ``RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR``);
+only B doubles come back.
 
 Same signature as the reference.  Extension: a leading batch axis on ``ode_init`` / ``prior_pars`` / ``**params``
 (observations are shared) returns an array (B,).  Restrictions of this build: ``kalman_type="standard"``, scalar
@@ -28,8 +29,14 @@ def fenrir(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogat
     if D.ndim != 4 or D.shape[2] != 1 or Om.shape != D.shape[:2] + (1, 1) or obs.shape != D.shape[:2] + (1,):
         raise ValueError("fenrir: obs_data (n_obs, n_block, 1), obs_weight (n_obs, n_block, 1, n_bstate), obs_var "
                          "(n_obs, n_block, 1, 1) -- scalar observations per block in this build")
-    plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
-                     store_pred=True, batch_minor=True, **params)
+    # the MFMA-tile forward kernels when the configuration has them (n_bstate = 3: the backward pass then re-evaluates
+    # the predicted moments from the filtered tiles), else the lane-per-trajectory kernels with stored predictions
+    plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, **params)
+    lay = C.c_int32(0)
+    _lib.check(plan.dev.lib.rk_solve_layout(C.byref(plan.cfg), _lib.MODE_FILTER, C.byref(lay)))
+    if lay.value != _lib.LAYOUT_TILE3:
+        plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
+                         store_pred=True, batch_minor=True, **params)
     if D.shape[1:] != (plan.d, 1, plan.p):
         raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, 1, {plan.p})")
     ind = obs_index(t_min, t_max, n_steps, obs_times)             # fenrir.py:118-120

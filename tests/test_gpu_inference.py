@@ -209,3 +209,27 @@ def test_config4_full_size_per_gpu(ra):
                           theta=theta[sl])
         p1.sim(20242)
         np.testing.assert_array_equal(p1.x_host()[0], x[b])
+
+
+@pytest.mark.parametrize("p", [3, 4])
+def test_fenrir_long_horizon_sparse_observations(ra, p):
+    """Fenrir with few observations on a long grid: at n_bstate = 3 the MFMA-tile kernels (forward tiles, backward filter
+    with whole 16-step chunks between observations); at n_bstate = 4 the lane-per-trajectory kernels with stored
+    predictions.  Batch of 5 against the oracle."""
+    from oracle import fenrir as ofen
+    N, t_max, n_obs, B = 200, 10.0, 4, 5
+    rng = np.random.default_rng(7)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0 = init(np.array([-1., 1.]) + 0.05 * rng.standard_normal((B, 2)), 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / N, p, np.array([.1, .1]))
+    obs_times = np.array([0.0, 3.35, 7.5, 10.0])
+    y = rng.standard_normal((n_obs, 2, 1))
+    Dw = np.zeros((n_obs, 2, 1, p)); Dw[..., 0] = 1.0; Dw[..., 1] = 0.3
+    Om = np.full((n_obs, 2, 1, 1), 0.05)
+    args = (W, x0, 0.0, t_max, N)
+    val = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, prior, y, obs_times,
+                              Dw, Om, theta=theta)
+    ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
+    assert val.shape == (B,)
+    np.testing.assert_allclose(val, ref, rtol=1e-7, atol=1e-7)
