@@ -104,22 +104,24 @@ def main():
     dist = None
     comm = "none"
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        comm = "gloo"
+        sys.stdout.flush()
         saved_stdout = os.dup(1)
-        os.dup2(2, 1)                     # RCCL prints diagnostics on stdout; keep stdout for the one JSON line
+        os.dup2(2, 1)                     # gloo and RCCL print diagnostics on stdout; keep stdout for the one JSON line
         try:
-            uid = (C.c_char * _lib.COMM_UID_BYTES)()
-            if rank == 0:
-                _lib.check(lib.rk_comm_uid(uid))
-            box = [bytes(uid)]
-            dist.broadcast_object_list(box, src=0)
-            uid = (C.c_char * _lib.COMM_UID_BYTES).from_buffer_copy(box[0])
-            _lib.check(lib.rk_comm_init(dev.h, rank, world, uid))
-            comm = "rccl"
-        except Exception as e:
-            print(f"[rank {rank}] RCCL communicator unavailable ({e}); using gloo for barriers", file=sys.stderr)
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            comm = "gloo"
+            try:
+                uid = (C.c_char * _lib.COMM_UID_BYTES)()
+                if rank == 0:
+                    _lib.check(lib.rk_comm_uid(uid))
+                box = [bytes(uid)]
+                dist.broadcast_object_list(box, src=0)
+                uid = (C.c_char * _lib.COMM_UID_BYTES).from_buffer_copy(box[0])
+                _lib.check(lib.rk_comm_init(dev.h, rank, world, uid))
+                comm = "rccl"
+            except Exception as e:
+                print(f"[rank {rank}] RCCL communicator unavailable ({e}); using gloo for barriers", file=sys.stderr)
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
