@@ -10,6 +10,7 @@ Same signature as the reference.  Extension: a leading batch axis on ``ode_init`
 (observations are shared) returns an array (B,).  Restrictions of this build: ``kalman_type="standard"``, scalar
 observations per block (``obs_weight`` (n_obs, n_block, 1, n_bstate), ``obs_var`` (n_obs, n_block, 1, 1)).
 """
+import collections
 import ctypes as C
 import numpy as np
 from .. import _lib
@@ -29,25 +30,55 @@ def fenrir(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogat
     if D.ndim != 4 or D.shape[2] != 1 or Om.shape != D.shape[:2] + (1, 1) or obs.shape != D.shape[:2] + (1,):
         raise ValueError("fenrir: obs_data (n_obs, n_block, 1), obs_weight (n_obs, n_block, 1, n_bstate), obs_var "
                          "(n_obs, n_block, 1, 1) -- scalar observations per block in this build")
-    # the MFMA-tile forward kernels when the configuration has them (n_bstate = 3: the backward pass then re-evaluates
-    # the predicted moments from the filtered tiles), else the lane-per-trajectory kernels with stored predictions
+    ind = obs_index(t_min, t_max, n_steps, obs_times)             # fenrir.py:118-120
+    if np.any(np.diff(ind) < 0):
+        raise ValueError("obs_times must be ascending")
+    plan = _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params)
+    if D.shape[1:] != (plan.d, 1, plan.p):
+        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, 1, {plan.p})")
+    plan.filter(key)
+    dev = plan.dev
+    # observations live on the plan and are uploaded again only when they change (a sampler calls this once per step)
+    cache = plan.__dict__.setdefault("_fenrir_obs", {})
+    sig = (obs.tobytes(), D.tobytes(), Om.tobytes(), ind.tobytes())
+    if cache.get("sig") != sig:
+        cache["sig"] = sig
+        cache["dev"] = tuple(dev.to_device(np.ascontiguousarray(a)) for a in
+                             (obs[:, :, 0], D[:, :, 0, :], Om[:, :, 0, 0], ind.astype(np.int32)))
+    d_obs, d_w, d_v, d_ind = cache["dev"]
+    out = dev.empty((plan.B,))
+    _lib.check(dev.lib.rk_fenrir_backward(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(plan._out), d_obs.ptr,
+                                          d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), out.ptr))
+    ll = out.to_host()
+    return ll if plan.batched else float(ll[0])
+
+
+_plans = collections.OrderedDict()          # a few device-resident plans, reused when only the numbers change
+
+
+def _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params):
+    """The device-resident ``SolvePlan`` of a previous call with the same static configuration (ODE, grid, interrogation,
+    weight matrix, array shapes) with its inputs replaced in place, or a new one.  The MFMA-tile forward kernels are used
+    when the configuration has them (n_bstate = 3: the backward pass then re-evaluates the predicted moments from the
+    filtered tiles), else the lane-per-trajectory kernels with stored predictions."""
+    W = np.asarray(ode_weight, dtype=np.float64)
+    shapes = tuple((k, np.shape(v)) for k, v in sorted(params.items()))
+    itg = getattr(interrogate, "func", interrogate), tuple(sorted(getattr(interrogate, "keywords", {}).items()))
+    key = (id(ode_fun), W.shape, W.tobytes(), np.shape(ode_init), tuple(np.shape(a) for a in prior_pars), float(t_min),
+           float(t_max), int(n_steps), itg, kalman_type, shapes)
+    plan = _plans.get(key)
+    if plan is not None:
+        _plans.move_to_end(key)
+        plan.update(ode_init=ode_init, prior_pars=prior_pars, **params)
+        return plan
     plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, **params)
     lay = C.c_int32(0)
     _lib.check(plan.dev.lib.rk_solve_layout(C.byref(plan.cfg), _lib.MODE_FILTER, C.byref(lay)))
     if lay.value != _lib.LAYOUT_TILE3:
         plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
                          store_pred=True, batch_minor=True, **params)
-    if D.shape[1:] != (plan.d, 1, plan.p):
-        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, 1, {plan.p})")
-    ind = obs_index(t_min, t_max, n_steps, obs_times)             # fenrir.py:118-120
-    if np.any(np.diff(ind) < 0):
-        raise ValueError("obs_times must be ascending")
-    plan.filter(key)
-    dev = plan.dev
-    d_obs, d_w, d_v, d_ind = (dev.to_device(np.ascontiguousarray(a)) for a in
-                              (obs[:, :, 0], D[:, :, 0, :], Om[:, :, 0, 0], ind.astype(np.int32)))
-    out = dev.empty((plan.B,))
-    _lib.check(dev.lib.rk_fenrir_backward(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(plan._out), d_obs.ptr,
-                                          d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), out.ptr))
-    ll = out.to_host()
-    return ll if plan.batched else float(ll[0])
+    plan._keep_ode = ode_fun                 # the key holds id(ode_fun): keep the object alive with the plan
+    _plans[key] = plan
+    while len(_plans) > 4:
+        _plans.popitem(last=False)
+    return plan
