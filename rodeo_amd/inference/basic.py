@@ -10,7 +10,7 @@ Returns the log-likelihood(s): a float, or an array of shape (B,) for batched in
 """
 import numpy as np
 from .. import _lib
-from ..solve import SolvePlan
+from ..solve import cached_plan
 from .logpost import gauss_obs_logpost, obs_index
 
 
@@ -27,8 +27,8 @@ class GaussianObsLoglik:
 
 def basic(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars,
           obs_data, obs_times, obs_loglik, kalman_type="standard", **params):
-    plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
-                     **params)
+    plan = cached_plan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
+                       **params)        # device buffers are reused across calls with the same configuration
     plan.mv(key)
     ind = obs_index(t_min, t_max, n_steps, obs_times)             # basic.py:61-62
     if isinstance(obs_loglik, GaussianObsLoglik):

@@ -10,11 +10,10 @@ Same signature as the reference.  Extension: a leading batch axis on ``ode_init`
 (observations are shared) returns an array (B,).  Restrictions of this build: ``kalman_type="standard"``, scalar
 observations per block (``obs_weight`` (n_obs, n_block, 1, n_bstate), ``obs_var`` (n_obs, n_block, 1, 1)).
 """
-import collections
 import ctypes as C
 import numpy as np
 from .. import _lib
-from ..solve import SolvePlan
+from ..solve import cached_plan
 from .logpost import obs_index
 
 
@@ -53,32 +52,14 @@ def fenrir(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogat
     return ll if plan.batched else float(ll[0])
 
 
-_plans = collections.OrderedDict()          # a few device-resident plans, reused when only the numbers change
-
-
 def _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params):
-    """The device-resident ``SolvePlan`` of a previous call with the same static configuration (ODE, grid, interrogation,
-    weight matrix, array shapes) with its inputs replaced in place, or a new one.  The MFMA-tile forward kernels are used
-    when the configuration has them (n_bstate = 3: the backward pass then re-evaluates the predicted moments from the
-    filtered tiles), else the lane-per-trajectory kernels with stored predictions."""
-    W = np.asarray(ode_weight, dtype=np.float64)
-    shapes = tuple((k, np.shape(v)) for k, v in sorted(params.items()))
-    itg = getattr(interrogate, "func", interrogate), tuple(sorted(getattr(interrogate, "keywords", {}).items()))
-    key = (id(ode_fun), W.shape, W.tobytes(), np.shape(ode_init), tuple(np.shape(a) for a in prior_pars), float(t_min),
-           float(t_max), int(n_steps), itg, kalman_type, shapes)
-    plan = _plans.get(key)
-    if plan is not None:
-        _plans.move_to_end(key)
-        plan.update(ode_init=ode_init, prior_pars=prior_pars, **params)
-        return plan
-    plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, **params)
+    """A (cached, solve.cached_plan) plan on the MFMA-tile forward kernels when the configuration has them (n_bstate = 3:
+    the backward pass then re-evaluates the predicted moments from the filtered tiles), else on the lane-per-trajectory
+    kernels with stored predictions."""
+    args = (ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type)
+    plan = cached_plan(*args, **params)
     lay = C.c_int32(0)
     _lib.check(plan.dev.lib.rk_solve_layout(C.byref(plan.cfg), _lib.MODE_FILTER, C.byref(lay)))
     if lay.value != _lib.LAYOUT_TILE3:
-        plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
-                         store_pred=True, batch_minor=True, **params)
-    plan._keep_ode = ode_fun                 # the key holds id(ode_fun): keep the object alive with the plan
-    _plans[key] = plan
-    while len(_plans) > 4:
-        _plans.popitem(last=False)
+        plan = cached_plan(*args, store_pred=True, batch_minor=True, **params)
     return plan

@@ -19,6 +19,7 @@ Differences from the reference that a caller can see:
   * ``key`` is an integer seed (or ``None``) for a Philox counter stream instead of a JAX threefry key -- draws have
     the reference's law, not its bit-stream ("parity unpinned" for draws).
 """
+import collections
 import ctypes as C
 import functools
 import numpy as np
@@ -239,6 +240,36 @@ class SolvePlan:
     def bytes_per_traj_step(self, kind="mv"):
         d, p = self.d, self.p
         return 3 * d * p * (p + 1) * 8 if kind == "mv" else (2 * d * p * (p + 1) + d * p) * 8
+
+
+_plan_cache = collections.OrderedDict()     # a few device-resident plans, reused when only the numbers change
+
+
+def cached_plan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type="standard",
+                store_pred=False, batch_minor=False, **params):
+    """
+    The device-resident ``SolvePlan`` of an earlier call with the same static configuration (ODE, grid, interrogation,
+    weight matrix, array shapes, flags) with its inputs replaced in place (``SolvePlan.update``), or a new one.  For the
+    callers that bring back a few doubles per trajectory and are called in a loop (``inference.basic``, ``fenrir``):
+    rebuilding the plan would cost more than the kernels.  At most four plans are kept.
+    """
+    W = np.asarray(ode_weight, dtype=np.float64)
+    shapes = tuple((k, np.shape(v)) for k, v in sorted(params.items()))
+    itg = getattr(interrogate, "func", interrogate), tuple(sorted(getattr(interrogate, "keywords", {}).items()))
+    key = (id(ode_fun), W.shape, W.tobytes(), np.shape(ode_init), tuple(np.shape(a) for a in prior_pars), float(t_min),
+           float(t_max), int(n_steps), itg, kalman_type, bool(store_pred), bool(batch_minor), shapes)
+    plan = _plan_cache.get(key)
+    if plan is not None:
+        _plan_cache.move_to_end(key)
+        plan.update(ode_init=ode_init, prior_pars=prior_pars, **params)
+        return plan
+    plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
+                     store_pred=store_pred, batch_minor=batch_minor, **params)
+    plan._keep_ode = ode_fun                 # the key holds id(ode_fun): keep the object alive with the plan
+    _plan_cache[key] = plan
+    while len(_plan_cache) > 4:
+        _plan_cache.popitem(last=False)
+    return plan
 
 
 def _solve_filter(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate,
