@@ -233,3 +233,26 @@ def test_fenrir_long_horizon_sparse_observations(ra, p):
     ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
     assert val.shape == (B,)
     np.testing.assert_allclose(val, ref, rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("N", [1, 2, 16, 17, 18, 33])
+def test_fenrir_tile_short_horizons(ra, N):
+    """Chunk / pipeline boundaries of the tile backward filter: horizons around the 16-step chunk size, observations at
+    both ends and (when there is room) in between, three trajectories (ragged tile-waves)."""
+    from oracle import fenrir as ofen
+    t_max, B = 0.05 * N, 3
+    rng = np.random.default_rng(100 + N)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
+    x0 = init(np.array([-1., 1.]) + 0.05 * rng.standard_normal((B, 2)), 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / N, 3, np.array([.1, .1]))
+    obs_times = np.unique(np.array([0.0, 0.05 * (N // 2), t_max]))
+    n_obs = len(obs_times)
+    y = rng.standard_normal((n_obs, 2, 1))
+    Dw = np.zeros((n_obs, 2, 1, 3)); Dw[..., 0] = 1.0
+    Om = np.full((n_obs, 2, 1, 1), 0.01)
+    args = (W, x0, 0.0, t_max, N)
+    val = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, prior, y, obs_times,
+                              Dw, Om, theta=theta)
+    ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
+    np.testing.assert_allclose(val, ref, rtol=1e-7, atol=1e-7)
