@@ -114,6 +114,14 @@ __device__ __forceinline__ double exp(double x) { return ::exp(x); }
 __device__ __forceinline__ double log(double x) { return ::log(x); }
 __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
 __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
+__device__ __forceinline__ double tan(double x) { return ::tan(x); }
+__device__ __forceinline__ double sinh(double x) { return ::sinh(x); }
+__device__ __forceinline__ double cosh(double x) { return ::cosh(x); }
+__device__ __forceinline__ double atan(double x) { return ::atan(x); }
+__device__ __forceinline__ double asin(double x) { return ::asin(x); }
+__device__ __forceinline__ double acos(double x) { return ::acos(x); }
+__device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
+__device__ __forceinline__ double expm1(double x) { return ::expm1(x); }
 
 #define RK_DUAL_FUN(NAME, VEXPR, DFAC)                                      \
     template <int P>                                                         \
@@ -130,6 +138,14 @@ RK_DUAL_FUN(exp, ::exp(a.v), r.v)
 RK_DUAL_FUN(log, ::log(a.v), 1.0 / a.v)
 RK_DUAL_FUN(sqrt, ::sqrt(a.v), 0.5 / r.v)
 RK_DUAL_FUN(tanh, ::tanh(a.v), 1.0 - r.v * r.v)
+RK_DUAL_FUN(tan, ::tan(a.v), 1.0 + r.v * r.v)
+RK_DUAL_FUN(sinh, ::sinh(a.v), ::cosh(a.v))
+RK_DUAL_FUN(cosh, ::cosh(a.v), ::sinh(a.v))
+RK_DUAL_FUN(atan, ::atan(a.v), 1.0 / (1.0 + a.v * a.v))
+RK_DUAL_FUN(asin, ::asin(a.v), 1.0 / ::sqrt(1.0 - a.v * a.v))
+RK_DUAL_FUN(acos, ::acos(a.v), -1.0 / ::sqrt(1.0 - a.v * a.v))
+RK_DUAL_FUN(log1p, ::log1p(a.v), 1.0 / (1.0 + a.v))
+RK_DUAL_FUN(expm1, ::expm1(a.v), r.v + 1.0)
 #undef RK_DUAL_FUN
 
 // Adapter: a scalar-generic `rhs` -> the (f, fjac) interface of csrc/rhs.hpp

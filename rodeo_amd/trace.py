@@ -3,7 +3,8 @@ Python right-hand sides on the device: ``ode.from_python`` TRACES an ordinary ``
 with NumPy exactly like the JAX functions of the reference (README.md:92-99, docs/examples/lorenz.md:85-92) -- into the
 scalar-generic HIP ``rhs`` that ``ode.from_source`` compiles with hiprtc.  This is what JAX does with the callable
 inside ``lax.scan`` (src/rodeo/solve.py:70-78): the function is run once on symbolic inputs; arithmetic, indexing,
-``np.array([...])`` and the elementary functions are recorded; data-dependent Python control flow cannot be traced
+``np.array([...])``, powers and the elementary functions (sin, cos, tan, exp, log, sqrt, tanh, sinh, cosh, arctan,
+arcsin, arccos, log1p, expm1) are recorded; data-dependent Python control flow cannot be traced
 (neither can it under ``jax.jit``).  The Jacobian that ``interrogate_kramer`` needs comes from forward-mode duals on
 the generated code, the counterpart of ``jax.jacfwd`` (src/rodeo/interrogate.py:76).
 
@@ -14,7 +15,10 @@ import hashlib
 import numbers
 import numpy as np
 
-_FUNCS = ("sin", "cos", "exp", "log", "sqrt", "tanh")
+# NumPy ufunc (method looked up on object arrays) -> device function (rodeo_amd/csrc/dual.hpp)
+_FUNCS = {"sin": "sin", "cos": "cos", "tan": "tan", "exp": "exp", "log": "log", "sqrt": "sqrt", "tanh": "tanh",
+          "sinh": "sinh", "cosh": "cosh", "arctan": "atan", "arcsin": "asin", "arccos": "acos", "log1p": "log1p",
+          "expm1": "expm1"}
 
 
 def _lit(v):
@@ -89,14 +93,14 @@ class Sym:
     __float__ = __int__ = _cmp
 
 
-def _make_fun(name):
+def _make_fun(cname):
     def method(self):
-        return Sym(f"{name}({self.code})")
+        return Sym(f"{cname}({self.code})")
     return method
 
 
-for _n in _FUNCS:                                        # np.sin(object array) calls element.sin()
-    setattr(Sym, _n, _make_fun(_n))
+for _n, _c in _FUNCS.items():                            # np.sin(object array) calls element.sin()
+    setattr(Sym, _n, _make_fun(_c))
 
 
 def _symbols(shape, fmt):

@@ -354,3 +354,24 @@ def test_traced_higher_order_example(ra):
     x = ra.solve_sim(11, higher_fun, W, x0, 0., t_max, N, g, prior)
     xo = scan.solve_sim(11, odes.higher_order, W, x0, 0., t_max, N, o, prior)
     assert x.shape == (N + 1, 1, 4) and np.max(np.abs(x - xo)) < 1e-7
+
+
+def test_traced_elementary_functions_and_their_derivatives(ra):
+    """Every elementary function the tracer knows, in one right-hand side: interrogate_kramer needs the derivative of
+    each (forward-mode duals, dual.hpp) -- against the oracle with a complex-step Jacobian of the same Python function."""
+    def fun(X, t, **params):
+        x, y = X[:, 0]
+        k = params["k"]
+        fx = (np.arctan(x) - np.sinh(0.3 * y) * np.cos(t) + np.log1p(x * x) - 0.2 * np.expm1(-x) + np.tan(0.1 * x)
+              + np.arcsin(0.5 * np.tanh(y)) - k[0] * x ** 3 + np.sqrt(1.0 + y ** 2) - np.exp(-x * x))
+        fy = np.arccos(0.3 * np.sin(x)) - np.cosh(0.2 * y) + np.log(2.0 + np.cos(y)) - k[1] * y + 1.5 ** (0.1 * x) + y ** 1.5 / (1.0 + y ** 2.0)
+        return np.array([[fx], [fy]])
+    k = np.array([0.3, 0.8])
+    N, t_max = 80, 2.0
+    W, init = ra.utils.first_order_pad(fun, 2, 3)
+    x0 = init(np.array([0.4, 0.7]), 0.0, k=k)
+    prior = ra.ibm_init(t_max / N, 3, np.array([.1, .1]))
+    m, v = ra.solve_mv(None, fun, W, x0, 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior, k=k)
+    mo, vo = scan.solve_mv(None, _oracle_ode("funcs", fun, 2), W, x0, 0.0, t_max, N, oi.interrogate_kramer, prior, k=k)
+    assert np.all(np.isfinite(mo)) and np.max(np.abs(m - mo)) < 1e-9 * max(1.0, np.max(np.abs(mo)))
+    assert np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))
