@@ -515,3 +515,23 @@ def test_config3_full_size_properties(ra):
         assert np.all(np.isfinite(ms)) and np.all(np.isfinite(vs))
         assert np.max(np.abs(vs - np.swapaxes(vs, -1, -2))) <= 1e-12 * np.max(np.abs(vs))
         assert np.max(np.abs(ms[:, :, :, 0])) < 100.0                     # on the attractor
+
+
+def test_integration_md_stub_runs(ra):
+    """The ctypes stub printed in INTEGRATION.md (section 2), executed as it stands (only the library path is filled in),
+    gives the numbers of rodeo_amd.solve_mv: the documented binding is a working one."""
+    import os, re
+    from rodeo_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, numpy as np.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("librodeo_kalman.so")', f'C.CDLL({os.path.join(root, "rodeo_amd", "librodeo_kalman.so")!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    B = 5
+    s = fitz_problem(ra, N=40, t_max=2.0, sigma=.1, B=B)
+    m, v = ns["solve_mv"](None, _lib.RHS_FITZHUGH_NAGUMO, s["W"], s["x0"], 0.0, 2.0, 40, _lib.INTERROGATE_KRAMER,
+                          s["prior"], s["theta"])
+    m2, v2 = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, 2.0, 40, ra.interrogate.interrogate_kramer,
+                         s["prior"], theta=s["theta"])
+    assert m.shape == m2.shape and np.max(np.abs(m - m2)) < 1e-9 and np.max(np.abs(v - v2)) < 1e-9 * np.max(np.abs(v2))
