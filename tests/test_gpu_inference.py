@@ -256,3 +256,30 @@ def test_fenrir_tile_short_horizons(ra, N):
                               Dw, Om, theta=theta)
     ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
     np.testing.assert_allclose(val, ref, rtol=1e-7, atol=1e-7)
+
+
+def test_fenrir_lorenz_three_blocks(ra):
+    """docs/examples/lorenz.md's setting (Lorenz63, n_deriv = 3, three variables) through fenrir: tiles of one trajectory
+    spread over tile-waves (three blocks, four tiles per wave), built-in functor and the traced Python function."""
+    from oracle import fenrir as ofen
+
+    def lorenz(X, t, **params):
+        rho, sigma, beta = params["theta"]
+        x, y, z = X[:, 0]
+        return np.array([[-sigma * x + sigma * y], [rho * x - y - x * z], [-beta * z + x * y]])
+    N, t_max, B = 120, 0.6, 6
+    rng = np.random.default_rng(5)
+    theta = np.array([28., 10., 8. / 3.]) * np.exp(0.01 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, 3)
+    x0 = init(np.array([-12., -5., 38.]) + 0.1 * rng.standard_normal((B, 3)), 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / N, 3, np.array([5e7] * 3))
+    obs_times = np.linspace(0, t_max, 7)
+    n_obs = len(obs_times)
+    y = np.array([-12., -5., 38.])[None, :, None] + rng.standard_normal((n_obs, 3, 1))
+    Dw = np.zeros((n_obs, 3, 1, 3)); Dw[..., 0] = 1.0
+    Om = np.full((n_obs, 3, 1, 1), 0.25)
+    args = (W, x0, 0.0, t_max, N)
+    ref = ofen.fenrir(None, odes.lorenz63, *args, oi.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
+    for fun in (ra.ode.lorenz63, lorenz):
+        val = ra.inference.fenrir(None, fun, *args, ra.interrogate.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
+        np.testing.assert_allclose(val, ref, rtol=1e-7, atol=1e-6)
