@@ -6,12 +6,42 @@ Same signature as the reference.  ``obs_loglik`` may be
   * ``GaussianObsLoglik(noise_sd)`` -- reduced on the device (``rk_gauss_obs_logpost``), only B doubles come back;
   * any Python callable ``obs_loglik(obs_data, ode_data, **params)`` with the reference's meaning -- then only the
     ``n_obs`` needed time slices are downloaded and the callable runs on the host per trajectory.
-Returns the log-likelihood(s): a float, or an array of shape (B,) for batched inputs.
+Returns ``(loglik, Xt)`` like the reference's code (basic.py:62; its docstring mentions only the first): the
+log-likelihood -- a float, or an array of shape (B,) for batched inputs -- and the posterior mean ``Xt`` of ``solve_mv``.
+``Xt`` is a ``LazyMean``: the megabytes stay on the device unless it is actually used (``np.asarray(Xt)``, indexing);
+the device buffers are reused by the next call with the same configuration, after which an unread ``Xt`` is stale.
 """
 import numpy as np
 from .. import _lib
 from ..solve import cached_plan
 from .logpost import gauss_obs_logpost, obs_index
+
+
+class LazyMean:
+    """The posterior mean of the solve behind a ``basic`` call, downloaded on first use."""
+
+    def __init__(self, plan):
+        self._plan, self._gen, self._val = plan, plan.__dict__.get("_generation", 0), None
+
+    def _get(self):
+        if self._val is None:
+            if self._plan.__dict__.get("_generation", 0) != self._gen:
+                raise RuntimeError("this Xt belongs to an earlier call: its device buffers have been reused; read it "
+                                   "(np.asarray(Xt)) before calling basic() again with the same configuration")
+            self._val = np.ascontiguousarray(self._plan.state_host()[0])
+        return self._val
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._get()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, idx):
+        return self._get()[idx]
+
+    @property
+    def shape(self):
+        p = self._plan
+        return ((p.B,) if p.batched else ()) + (p.N + 1, p.d, p.p)
 
 
 class GaussianObsLoglik:
@@ -29,11 +59,13 @@ def basic(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate
           obs_data, obs_times, obs_loglik, kalman_type="standard", **params):
     plan = cached_plan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
                        **params)        # device buffers are reused across calls with the same configuration
+    plan.__dict__["_generation"] = plan.__dict__.get("_generation", 0) + 1
     plan.mv(key)
+    Xt = LazyMean(plan)
     ind = obs_index(t_min, t_max, n_steps, obs_times)             # basic.py:61-62
     if isinstance(obs_loglik, GaussianObsLoglik):
         ll = gauss_obs_logpost(plan, obs_data, ind, obs_loglik.noise_sd).to_host()
-        return ll if plan.batched else float(ll[0])
+        return (ll if plan.batched else float(ll[0])), Xt
     # generic callable: fetch only the observed time slices
     rows = []
     for n in ind:
@@ -48,4 +80,4 @@ def basic(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate
     ode_data = np.stack(rows, axis=1)                              # (B, n_obs, d, p)
     out = np.array([obs_loglik(obs_data, ode_data[b], **{k: (np.asarray(v)[b] if np.ndim(v) >= 2 else v)
                                                           for k, v in params.items()}) for b in range(plan.B)])
-    return out if plan.batched else out[0]
+    return (out if plan.batched else out[0]), Xt

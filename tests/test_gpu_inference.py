@@ -38,7 +38,7 @@ def test_basic_gaussian_and_callable(ra):
     sd = np.sqrt(0.005)
     args = (None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0., s["t_max"], s["N"], ra.interrogate.interrogate_kramer,
             s["prior"], s["Y"], s["obs_times"])
-    ll_dev = ra.inference.basic(*args, GaussianObsLoglik(sd), theta=s["theta"])
+    ll_dev, Xt = ra.inference.basic(*args, GaussianObsLoglik(sd), theta=s["theta"])     # (loglik, Xt): basic.py:62
     mo, _ = scan.solve_mv(None, odes.fitzhugh_nagumo, s["W"], s["x0"], 0., s["t_max"], s["N"], oi.interrogate_kramer,
                           s["prior"], theta=s["theta"])
     ll_ref = np.sum(norm.logpdf(s["Y"], loc=mo[s["ind"], :, 0], scale=sd))
@@ -46,20 +46,28 @@ def test_basic_gaussian_and_callable(ra):
     # an arbitrary Python obs_loglik with the reference's signature
     def my_loglik(obs_data, ode_data, **params):
         return np.sum(norm.logpdf(obs_data, loc=ode_data[:, :, 0], scale=sd))
-    ll_call = ra.inference.basic(*args, my_loglik, theta=s["theta"])
+    assert Xt.shape == mo.shape and np.max(np.abs(np.asarray(Xt) - mo)) < 1e-9 and np.max(np.abs(Xt[-1] - mo[-1])) < 1e-9
+    ll_call, _ = ra.inference.basic(*args, my_loglik, theta=s["theta"])
     assert abs(ll_call - ll_ref) < 1e-7 * max(1.0, abs(ll_ref))
     # batched (tile layout inside): B trajectories
     B = 5
     th = s["theta"] * np.exp(0.05 * np.random.default_rng(0).standard_normal((B, 3)))
     _, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)
     x0 = init(np.tile([-1., 1.], (B, 1)), 0., theta=th)
-    llb = ra.inference.basic(None, ra.ode.fitzhugh_nagumo, s["W"], x0, 0., s["t_max"], s["N"],
+    llb, XtB = ra.inference.basic(None, ra.ode.fitzhugh_nagumo, s["W"], x0, 0., s["t_max"], s["N"],
                              ra.interrogate.interrogate_kramer, s["prior"], s["Y"], s["obs_times"],
                              GaussianObsLoglik(sd), theta=th)
     mB, _ = scan.solve_mv(None, odes.fitzhugh_nagumo, s["W"], x0, 0., s["t_max"], s["N"], oi.interrogate_kramer,
                           s["prior"], theta=th)
     ref = np.array([np.sum(norm.logpdf(s["Y"], loc=mB[b][s["ind"], :, 0], scale=sd)) for b in range(B)])
     np.testing.assert_allclose(llb, ref, rtol=1e-7, atol=1e-7)
+    assert XtB.shape == mB.shape and np.max(np.abs(np.asarray(XtB) - mB)) < 1e-9
+    with pytest.raises(RuntimeError):                                        # Xt of the first call: its buffers were reused
+        ra.inference.basic(*args, GaussianObsLoglik(sd), theta=s["theta"])
+        ra.inference.basic(*args, GaussianObsLoglik(sd), theta=s["theta"])[1]
+        stale = ra.inference.basic(*args, GaussianObsLoglik(sd), theta=s["theta"])[1]
+        ra.inference.basic(*args, GaussianObsLoglik(sd), theta=s["theta"])
+        np.asarray(stale)
 
 
 def test_chkrebtii_pseudo_marginal_logposterior(ra):
