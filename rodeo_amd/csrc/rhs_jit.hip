@@ -195,7 +195,7 @@ extern "C" {
 
 int rk_register_rhs_source(const char* type_name, const char* source, int32_t n_block, int32_t n_theta, int32_t* rhs_id) {
     RK_REQUIRE(type_name && source && rhs_id, RK_ERR_INVALID, "rk_register_rhs_source: null argument");
-    RK_REQUIRE(n_block >= 1 && n_block <= 8 && n_theta >= 0, RK_ERR_INVALID, "rk_register_rhs_source: bad n_block / n_theta");
+    RK_REQUIRE(n_block >= 1 && n_block <= 16 && n_theta >= 0, RK_ERR_INVALID, "rk_register_rhs_source: bad n_block / n_theta");
     std::lock_guard<std::mutex> lk(g_mu);
     g_rhs.push_back(UserRhs{type_name, source, n_block, n_theta});
     *rhs_id = RK_RHS_USER_BASE + (int)g_rhs.size() - 1;

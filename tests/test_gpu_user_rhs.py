@@ -375,3 +375,27 @@ def test_traced_elementary_functions_and_their_derivatives(ra):
     mo, vo = scan.solve_mv(None, _oracle_ode("funcs", fun, 2), W, x0, 0.0, t_max, N, oi.interrogate_kramer, prior, k=k)
     assert np.all(np.isfinite(mo)) and np.max(np.abs(m - mo)) < 1e-9 * max(1.0, np.max(np.abs(mo)))
     assert np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))
+
+
+@pytest.mark.parametrize("p", [3, 4])
+def test_traced_twelve_variable_system(ra, p):
+    """A traced right-hand side with twelve variables (a ring of coupled nonlinear oscillators): at n_deriv = 3 the tile
+    path with a three-wave workgroup per trajectory, at n_deriv = 4 the lane-per-trajectory kernels; against the oracle."""
+    d = 12
+
+    def ring(X, t, **params):
+        k, c = params["kc"]
+        x = X[:, 0]
+        return np.array([[k * (x[(i + 1) % d] - 2 * x[i] + x[(i - 1) % d]) - c * x[i] ** 3 + np.sin(t + i)] for i in range(d)])
+    B, N, t_max = 3, 48, 1.2
+    rng = np.random.default_rng(12)
+    kc = np.array([0.7, 0.2]) * np.exp(0.05 * rng.standard_normal((B, 2)))
+    dev = ra.ode.from_python(ring, d, kc=2)
+    W, init = ra.utils.first_order_pad(dev, d, p)
+    x0 = init(rng.standard_normal((B, d)), 0.0, kc=kc)
+    prior = ra.ibm_init(t_max / N, p, np.array([.1] * d))
+    m, v = ra.solve_mv(None, dev, W, x0, 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior, kc=kc)
+    o = _oracle_ode("ring", ring, d)
+    mo = np.stack([scan.solve_mv(None, o, W, x0[b], 0.0, t_max, N, oi.interrogate_kramer, prior, kc=kc[b])[0] for b in range(B)])
+    sm = np.max(np.abs(mo), axis=(0, 1, 2))
+    assert m.shape == mo.shape and np.max(np.abs(m - mo) / sm) < 1e-8
