@@ -8,9 +8,17 @@ def first_order_pad(ode_fun, n_vars, n_deriv):
     ``W[:, :, 1] = 1`` and ``ode_init(x0, t, **params) = [x0, f(x0, t), 0, ...]`` of shape (n_vars, n_deriv).
     ``x0`` may carry a leading batch axis (B, n_vars) together with batched parameters.
     """
+    from .ode import DeviceODE
+    fun = ode_fun
+    if not isinstance(ode_fun, DeviceODE) and callable(ode_fun):
+        # a plain Python right-hand side is written for ONE trajectory (X of shape (n_vars, n_deriv)): evaluate it per
+        # batch element instead of letting its indexing run over the batch axis
+        from .trace import _host_twin
+        fun = _host_twin(ode_fun, n_vars)
+
     def ode_init(x0, t, **params):
         x0 = np.asarray(x0, dtype=np.float64)[..., :, None]
-        f0 = ode_fun(x0, t, **params)
+        f0 = fun(x0, t, **params)
         lead = np.broadcast_shapes(x0.shape[:-2], f0.shape[:-2])
         x0 = np.broadcast_to(x0, lead + x0.shape[-2:])
         f0 = np.broadcast_to(f0, lead + f0.shape[-2:])

@@ -97,3 +97,20 @@ def test_trace_python_rhs_to_source_and_compile():
     assert ode(np.zeros((4, 2, 3)), 0.0, theta=np.ones((4, 3))).shape == (4, 2, 1)
     with pytest.raises(TypeError):
         trace.trace_source(lambda X, t: np.array([[abs(X[0, 0]) if X[0, 0] > 0 else 0.0]]), 1, 2, (), "Bad")
+
+
+def test_first_order_pad_with_plain_python_function_is_batch_safe():
+    """utils.first_order_pad on the reference's own kind of ode_fun (written for one trajectory): a batch of initial
+    values and parameters is evaluated per element, and equals the built-in functor's initialisation."""
+    import rodeo_amd as ra
+
+    def fitz_fun(X, t, **params):
+        a, b, c = params["theta"]
+        V, R = X[:, 0]
+        return np.array([[c * (V - V * V * V / 3 + R)], [-1 / c * (V - a + b * R)]])
+    W, init = ra.utils.first_order_pad(fitz_fun, 2, 3)
+    th = np.array([[.2, .2, 3.], [.3, .2, 2.]])              # B = 2 = n_vars: indexing over the batch axis would "work"
+    x0 = np.array([[-1., 1.], [0.5, 0.2]])
+    ref = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, 3)[1](x0, 0.0, theta=th)
+    np.testing.assert_allclose(init(x0, 0.0, theta=th), ref, rtol=1e-15)
+    assert init(x0[0], 0.0, theta=th[0]).shape == (2, 3) and W.shape == (2, 1, 3)
