@@ -855,20 +855,26 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                         w.Wt[e] = a.W[e] + (-Jij);                                   // W + wgt_meas   (solve.py:79)
                     }
                     __syncthreads();
-                    for (int i = threadIdx.x; i < m; i += DT) {
-                        double s = 0.0;
-                        for (int v = 0; v < m; ++v) {
+                    // f_i = sum_v A_iv x_v and yhat = W~ mu- + a ;  a = -f (+ J mu- for kramer, interrogate.py:81-82) with
+                    // J mu- = (W - W~) mu-: one wave per measurement row, lanes along the sums, wave reduction
+                    for (int i = threadIdx.x >> 6; i < m; i += DT / 64) {
+                        const int lane = threadIdx.x & 63;
+                        double s = 0.0, jm = 0.0, wm = 0.0;
+                        for (int v = lane; v < m; v += 64) {
                             const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
                             s = fma(Aiv, w.mup[(size_t)v * nd], s);
                         }
-                        // yhat = W~ mu- + a ;  a = -f (+ J mu- for kramer, interrogate.py:81-82) ; J mu- = (W - W~) mu-
-                        double jm = 0.0, wm = 0.0;
-                        for (int j = 0; j < p; ++j) {
-                            jm = fma(a.W[(size_t)i * p + j] - w.Wt[(size_t)i * p + j], w.mup[j], jm);
-                            wm = fma(w.Wt[(size_t)i * p + j], w.mup[j], wm);
+                        for (int j = lane; j < p; j += 64) {
+                            const double wt = w.Wt[(size_t)i * p + j], mj = w.mup[j];
+                            jm = fma(a.W[(size_t)i * p + j] - wt, mj, jm);
+                            wm = fma(wt, mj, wm);
+                        }
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) {
+                            s += __shfl_xor(s, off); jm += __shfl_xor(jm, off); wm += __shfl_xor(wm, off);
                         }
                         const double am = a.itg == RK_INTERROGATE_KRAMER ? -s + jm : -s;
-                        w.yhat[i] = wm + am;                                         // standard.py:93
+                        if (lane == 0) w.yhat[i] = wm + am;                           // standard.py:93
                     }
                     g = gemm_op(w.WS, p, w.Wt, p, false, w.A2, p, false, m, p, p, nullptr, 0, 0.0, 1.0);          // W~ Sigma-
                     break;
