@@ -170,3 +170,23 @@ def test_dense_general_prior_weight(ra):
     assert np.max(np.abs(m - mo) / np.maximum(scale_m, 1e-300)) < 1e-8
     dv = np.sqrt(np.abs(np.einsum("bnkii->bnki", vo)).max(axis=(0, 1, 2)))
     assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :] + 1e-300)) < 1e-6
+
+
+def test_dense_batched_ode_matrix(ra):
+    """A different matrix A per trajectory (parameter ``A`` of shape (B, n_vars, n_vars)): kramer over a few steps and
+    rodeo over a longer horizon against the oracle, trajectory by trajectory."""
+    n_vars, n_deriv, B = 6, 3, 4
+    for itg, N, tol in (("rodeo", 20, 1e-8), ("kramer", 5, 1e-7)):
+        t_max = N / 24.0
+        s = dense_problem(ra, n_vars, n_deriv, N, t_max, B=B)
+        rng = np.random.default_rng(11)
+        A = s["A"][None] + 0.05 * rng.standard_normal((B, n_vars, n_vars))
+        X0 = s["x0"].copy().reshape(B, n_vars, n_deriv)
+        X0[..., 1] = np.einsum("bij,bj->bi", A, X0[..., 0])
+        X0 = X0.reshape(B, 1, -1)
+        g, o = getattr(ra.interrogate, "interrogate_" + itg), getattr(oi, "interrogate_" + itg)
+        m, v = ra.solve_mv(None, ra.ode.linear_dense(n_vars, n_deriv), s["W"], X0, 0.0, t_max, N, g, s["prior"], A=A)
+        for b in range(B):
+            mo, vo = scan.solve_mv(None, odes.make_linear_dense(A[b], n_deriv), s["W"], X0[b], 0.0, t_max, N, o, s["prior"])
+            scale_m = np.max(np.abs(mo), axis=(0, 1))
+            assert np.max(np.abs(m[b] - mo) / np.maximum(scale_m, 1e-300)) < tol
