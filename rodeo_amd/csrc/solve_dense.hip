@@ -27,7 +27,7 @@
 // move the array to scratch (use selects / per-row state); all 120 LDS reads of a 16 x 16 triangular solve are issued
 // up front and spill unless each row's reads are tied to the previous result; a spill reload in a loop costs an
 // s_waitcnt vmcnt(0), i.e. it serialises every outstanding global load.
-// Measured on C5 (B = 256, p = 160, m = 32): 101 -> 48 ms per 50 steps = 19 % of the fp64 peak on the reference
+// Measured on C5 (B = 256, p = 160, m = 32): 101 -> 46 ms per 50 steps = 19.6 % of the fp64 peak on the reference
 // algorithm's flop count.  The phases now run at the chip's memory limit: a step moves ~8 MB per trajectory (the LU's
 // ten trailing updates alone 3 MB), 2 GB over the 256 workgroups, far beyond the L2s; the rank-16 updates reach
 // 7 TB/s aggregate.  Next step would be an LU whose [Sigma^- | T^T] stays in registers (200 tiles over 8 waves).
@@ -53,7 +53,7 @@ constexpr int DT = 512, NWAVE = DT / 64;
 // Optional phase timing (compile with -DRK_DENSE_STAMPS): cycles per phase, summed over the steps of workgroup 0,
 // in the spare doubles before the block-diagonal flag at the end of trajectory 0's workspace.
 #ifdef RK_DENSE_STAMPS
-#define RK_STAMP_DECL(ws_end) double* const stamps_ = (ws_end); long long stamp_t_ = __builtin_amdgcn_s_memtime()
+#define RK_STAMP_DECL(ws_end) double* const stamps_ = (double*)(ws_end); long long stamp_t_ = __builtin_amdgcn_s_memtime()
 #define RK_STAMP(k) do { __syncthreads(); if (stamps_ && blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); stamps_[-2 - (k)] += (double)(t_ - stamp_t_); stamp_t_ = t_; } } while (0)
 #define RK_STAMP_RESET() stamp_t_ = __builtin_amdgcn_s_memtime()
 #define RK_STAMP_ZERO() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 12; ++k_) stamps_[-2 - k_] = 0.0; __syncthreads(); } while (0)
@@ -73,12 +73,27 @@ __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 template <class T>
-__device__ __forceinline__ T* uni(T* ptr) {
+__device__ __forceinline__ T* uni(T* ptr) {                 // generic pointer (e.g. a descriptor on the caller's stack)
     const unsigned long long v = (unsigned long long)ptr;
     const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
     const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (T*)(((unsigned long long)hi_ << 32) | lo_);
 }
+// ... of a pointer into GLOBAL memory: rebuilt from scalars a generic pointer loses its address space and every access
+// through it becomes a flat load / store (64-bit per-lane address, both wait counters).  The result is therefore TYPED
+// as a global pointer (gd / cgd / gi below) and stays so through the helpers: scalar base + 32-bit lane offset.
+typedef __attribute__((address_space(1))) double gd;
+typedef __attribute__((address_space(1))) const double cgd;
+typedef __attribute__((address_space(1))) int gi;
+__device__ __forceinline__ unsigned long long uni_bits(const void* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi_ << 32) | lo_;
+}
+__device__ __forceinline__ gd* uni_g(double* ptr) { return (gd*)uni_bits(ptr); }
+__device__ __forceinline__ cgd* uni_g(const double* ptr) { return (cgd*)uni_bits(ptr); }
+__device__ __forceinline__ gi* uni_g(int* ptr) { return (gi*)uni_bits(ptr); }
 
 constexpr int LDS_DOUBLES = 16384;               // 128 KiB: GEMM staging / LU panel + U strip (one workgroup per CU)
 // The workgroup's LDS, at file scope so that the real (non-inlined) device functions below address it as LDS: through
@@ -117,7 +132,7 @@ static_assert(2 * G_KC * G_SP <= LDS_DOUBLES, "GEMM staging exceeds the LDS buff
 static_assert((G_MB / 16) * (G_MB / 16) <= G_TPW * NWAVE, "tiles per wave");
 
 // dst[k][j] = src[k * ld + j] for k < kn, j < jn; zero elsewhere in the 32 x 160 chunk  (source rows -> LDS rows)
-__device__ __forceinline__ void stage_rows(double* dst, const double* src, int ld, int kn, int jn) {
+__device__ __forceinline__ void stage_rows(double* dst, cgd* src, int ld, int kn, int jn) {
     constexpr int IT = G_KC * G_MB / DT;
     static_assert(IT * DT == G_KC * G_MB && IT % 5 == 0, "chunk size / workgroup size");
     for (int q0 = 0; q0 < IT; q0 += 5) {
@@ -135,7 +150,7 @@ __device__ __forceinline__ void stage_rows(double* dst, const double* src, int l
     }
 }
 // dst[k][i] = src[i * ld + k]  (source rows -> LDS columns): 8 lanes cover 32 consecutive k of one source row
-__device__ __forceinline__ void stage_cols(double* dst, const double* src, int ld, int kn, int in) {
+__device__ __forceinline__ void stage_cols(double* dst, cgd* src, int ld, int kn, int in) {
     for (int e = threadIdx.x; e < G_MB * 8; e += DT) {
         const int kg = e & 7, i = e >> 3;
         double v[4];
@@ -149,9 +164,9 @@ __device__ __forceinline__ void stage_cols(double* dst, const double* src, int l
 __device__ __noinline__ void wg_gemm(const GemmOp& g_) {
     double* const lds = g_lds;
     const GemmOp& gr = *uni(&g_);
-    GemmOp g;
-    g.C = uni(gr.C); g.ldc = uni(gr.ldc); g.A = uni(gr.A); g.lda = uni(gr.lda); g.B = uni(gr.B); g.ldb = uni(gr.ldb);
-    g.M = uni(gr.M); g.N = uni(gr.N); g.K = uni(gr.K); g.E = uni(gr.E); g.lde = uni(gr.lde);
+    struct { gd* C; cgd *A, *B, *E; int ldc, lda, ldb, lde, M, N, K; double ce, cab; bool ta, tb; } g;
+    g.C = uni_g(gr.C); g.ldc = uni(gr.ldc); g.A = uni_g(gr.A); g.lda = uni(gr.lda); g.B = uni_g(gr.B); g.ldb = uni(gr.ldb);
+    g.M = uni(gr.M); g.N = uni(gr.N); g.K = uni(gr.K); g.E = uni_g(gr.E); g.lde = uni(gr.lde);
     g.ce = uni(gr.ce); g.cab = uni(gr.cab); g.ta = uni((int)gr.ta) != 0; g.tb = uni((int)gr.tb) != 0;
     double* const As = lds;
     double* const Bs = lds + G_KC * G_SP;
@@ -438,14 +453,14 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
     const double* const us = g_lds + uni(us_off);
     const int lrows = uni(lrows_), nb = uni(nb_), usp = uni(usp_), rt = uni(rt_), ld1 = uni(ld1_), n1 = uni(n1_), ctA = uni(ctA_);
     const int ld2 = uni(ld2_), n2 = uni(n2_), ctB = uni(ctB_), offB = uni(offB_), mrows = uni(mrows_);
-    double* const C1 = uni(C1_);
-    double* const C2 = uni(C2_);
+    auto* const C1 = uni_g(C1_);
+    auto* const C2 = uni_g(C2_);
     const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
     const int nct = ctA + ctB, tiles = rt * nct;
     // Tiles wave, wave + 8, ... in groups of RU_G: the C values of the NEXT group are loaded before the current group is
     // multiplied and stored (a tile is 4 loads, 4 MFMAs, 4 stores; without this every tile waits a full memory round trip).
     constexpr int RU_G = 4;
-    auto tile_of = [&](int e, double*& Cm, int& ld, int& cj, int& sj, int& rb, bool& cok) {
+    auto tile_of = [&](int e, gd*& Cm, int& ld, int& cj, int& sj, int& rb, bool& cok) {
         rb = e / nct;
         const int ct = e - rb * nct;
         const bool inA = ct < ctA;
@@ -460,7 +475,7 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
         for (int u = 0; u < RU_G; ++u) {
             const int e = e0 + u * NWAVE;
             if (e < tiles) {
-                double* Cm; int ld, cj, sj, rb; bool cok;
+                gd* Cm; int ld, cj, sj, rb; bool cok;
                 tile_of(e, Cm, ld, cj, sj, rb, cok);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -478,7 +493,7 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
         for (int u = 0; u < RU_G; ++u) {
             const int e = e0 + u * NWAVE;
             if (e < tiles) {
-                double* Cm; int ld, cj, sj, rb; bool cok;
+                gd* Cm; int ld, cj, sj, rb; bool cok;
                 tile_of(e, Cm, ld, cj, sj, rb, cok);
                 const int li = min(rb * 16 + lo, lrows - 1);
                 d4 acc = cur[u];
@@ -504,7 +519,7 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
 // Net row permutation of one panel applied to `ncols` columns of M (row stride ld, rows relative to k0): one thread
 // per column loads the (at most 32) moved rows of its column and stores them to their new places -- no barrier, no
 // thread touches another thread's column.  Row bases are uniform (scalar), the column is the per-thread offset.
-__device__ __forceinline__ void lu_swap_cols(double* M, int ld, int ncols, int nm) {
+__device__ __forceinline__ void lu_swap_cols(gd* M, int ld, int ncols, int nm) {
     for (int cc = threadIdx.x; cc < ncols; cc += DT) {
         double tmp[2 * LU_NB];
 #pragma unroll
@@ -519,7 +534,7 @@ __device__ __forceinline__ void lu_swap_cols(double* M, int ld, int ncols, int n
 // X = L11^{-1} M for the 16-row block M (row stride ld, `ncols` columns; unit lower triangle from the LDS panel), one
 // thread per column; results to memory and to the LDS strip at column offset `soff` (zero in the padding columns up
 // to `npad` and in rows >= nb)
-__device__ __forceinline__ void lu_trsm_lower(double* M, int ld, int ncols, int npad, int nb, double* us, int usp, int soff) {
+__device__ __forceinline__ void lu_trsm_lower(gd* M, int ld, int ncols, int npad, int nb, double* us, int usp, int soff) {
     const double* const panel = g_lds;
     for (int c = threadIdx.x; c < npad; c += DT) {
         asm volatile("" ::: "memory");
@@ -548,7 +563,7 @@ __device__ __forceinline__ void lu_trsm_lower(double* M, int ld, int ncols, int 
 
 // X1 = U11^{-1} B1 for one 16-row block of the back substitution (U11 in the LDS panel buffer at rows k0..), one
 // thread per right-hand-side column; results to memory and to the LDS strip
-__device__ __forceinline__ void lu_trsm_upper(double* M, int ld, int k0, int nb, int nr, int nbp, double* us, int usp) {
+__device__ __forceinline__ void lu_trsm_upper(gd* M, int ld, int k0, int nb, int nr, int nbp, double* us, int usp) {
     const double* const panel = g_lds;
     for (int c = threadIdx.x; c < nbp; c += DT) {
         asm volatile("" ::: "memory");
@@ -573,19 +588,122 @@ __device__ __forceinline__ void lu_trsm_upper(double* M, int ld, int k0, int nb,
     }
 }
 
+// Back substitution  X = U^{-1} Y  with the whole right-hand side resident in registers (n, nr <= 160: at most 10 x 10
+// tiles of 16 x 16, wave w owns the tiles w, w + 8, ... in row-major order, 13 accumulators): Y is read once and X
+// written once, where the block-row loop over global memory moved 1.8 MB per solve at p = 160.  Per block row k from the
+// bottom: the block column of U is staged in LDS; the owners of row k put their tiles into per-column-tile LDS
+// scratches; 16 threads per column tile solve with U11 (the substitution of lu_trsm_upper, all ten tiles at once); the
+// owners take the solved tiles back and every wave updates its tiles above with rank-16 MFMAs (A fragments from the
+// staged block column, B fragments from the scratches).  Same operations in the same order as the block-row loop.
+constexpr int BS_T = 10, BS_Q = (BS_T * BS_T + NWAVE - 1) / NWAVE;
+constexpr int BS_SCR = BS_T * 16 * LU_LD;                 // doubles: panel region, then the ten scratches
+
+// threads 0 .. 16 nct - 1: X = U11^{-1} Y for column (tid & 15) of the tile in scratch (tid >> 4)
+__device__ __noinline__ void backsub_trsm_all(int k0_, int nb_, int nct_) {
+    const int k0 = uni(k0_), nb = uni(nb_), nct = uni(nct_);
+    if ((int)threadIdx.x >= 16 * nct) return;
+    const double* const panel = g_lds;
+    double* const scratch = g_lds + BS_SCR + (threadIdx.x >> 4) * 16 * LU_LD;
+    const int lo = threadIdx.x & 15;
+    double x[LU_NB];
+#pragma unroll
+    for (int j = 0; j < LU_NB; ++j) x[j] = j < nb ? scratch[j * LU_LD + lo] : 0.0;
+#pragma unroll
+    for (int j = LU_NB - 1; j >= 0; --j) {
+        int pj = (k0 + j) * LU_LD;
+        if (j < LU_NB - 1) asm("" : "+v"(pj) : "v"(x[j + 1]));          // (see lu_trsm_upper)
+        double sacc = x[j];
+#pragma unroll
+        for (int i = j + 1; i < LU_NB; ++i)
+            if (i < nb) sacc = fma(-panel[pj + i], x[i], sacc);
+        x[j] = j < nb ? sacc * g_rdiag[j] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < LU_NB; ++j) scratch[j * LU_LD + lo] = x[j];
+}
+
+__device__ __noinline__ void lu_backsub_regs(const double* A_, int lda_, double* Bm_, int ldb_, int n_, int nr_) {
+    auto* const A = uni_g(A_);
+    auto* const Bm = uni_g(Bm_);
+    const int lda = uni(lda_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
+    const int nbk = (n + 15) >> 4, nct = (nr + 15) >> 4;
+    double* const panel = g_lds;
+    double* const scr = g_lds + BS_SCR;
+    d4 t[BS_Q];
+#pragma unroll
+    for (int q = 0; q < BS_Q; ++q) {
+        const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * rb + 4 * v + hi, col = 16 * ct + lo;
+            double y = Bm[min(row, n - 1) * ldb + min(col, nr - 1)];            // clamped and unconditional: the loads stay batched
+            asm("" : "+v"(y));                                                  // (hipcc otherwise sinks each load into its own branch)
+            t[q][v] = (row < n && col < nr) ? y : 0.0;
+        }
+    }
+    for (int k = nbk - 1; k >= 0; --k) {
+        const int k0 = 16 * k, nb = min(16, n - k0);
+        __syncthreads();                                            // the previous block's panel and scratches are free
+        for (int e = threadIdx.x; e < (k0 + nb) * LU_NB; e += DT) {
+            const int r = e >> 4, c = e & 15;
+            panel[r * LU_LD + c] = c < nb ? A[r * lda + k0 + c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < BS_Q; ++q) {
+            const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+            if (rb == k && ct < nct) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) scr[ct * 16 * LU_LD + (4 * v + hi) * LU_LD + lo] = t[q][v];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < nb) g_rdiag[threadIdx.x] = 1.0 / panel[(k0 + threadIdx.x) * LU_LD + threadIdx.x];
+        __syncthreads();
+        backsub_trsm_all(k0, nb, nct);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BS_Q; ++q) {
+            const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+            if (ct < nct && rb <= k) {
+                const double* const sc = scr + ct * 16 * LU_LD;
+                if (rb == k) {                                      // the solved tile: X_k
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) t[q][v] = sc[(4 * v + hi) * LU_LD + lo];
+                } else {                                            // Y_rb -= U(rb, k) X_k
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+                        t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-panel[(16 * rb + lo) * LU_LD + 4 * kq + hi],
+                                                                    sc[(4 * kq + hi) * LU_LD + lo], t[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BS_Q; ++q) {
+        const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * rb + 4 * v + hi, col = 16 * ct + lo;
+            if (e < BS_T * BS_T && row < n && col < nr) Bm[row * ldb + col] = t[q][v];
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int ldb_, int n_, int nr_, int* piv_,
                                          double* ws_end_ = nullptr) {
     double* const lds = g_lds;
-    double* const A = uni(A_);
-    double* const Bm = uni(Bm_);
-    int* const piv = uni(piv_);
-    double* const ws_end = uni(ws_end_);
+    auto* const A = uni_g(A_);
+    auto* const Bm = uni_g(Bm_);
+    auto* const piv = uni_g(piv_);
+    auto* const ws_end = uni_g(ws_end_);
     (void)ws_end;
     const int lda = uni(lda_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
     RK_STAMP_DECL(ws_end);
     const int nrp = (n + 15) & ~15, nbp = (nr + 15) & ~15;      // strip: [0, nrt) trailing columns, [nrt, nrt + nbp) right-hand sides
     const int usp = (nrp + nbp + 16) | 1;                       // odd row stride
-    if (n > LU_MAXN || n * LU_LD + LU_NB * usp > LDS_DOUBLES) { wg_lu_solve_unblocked(lds, A, lda, Bm, ldb, n, nr, piv); return; }
+    if (n > LU_MAXN || n * LU_LD + LU_NB * usp > LDS_DOUBLES) { wg_lu_solve_unblocked(lds, (double*)A, lda, (double*)Bm, ldb, n, nr, (int*)piv); return; }
     double* const panel = lds;
     const int us_off = n * LU_LD;
     const int tid = threadIdx.x;
@@ -626,10 +744,15 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         RK_STAMP(3);
         if (n_right > 0)
             lu_rank_update(nb * LU_LD, n_right, nb, us_off, usp, (n_right + 15) >> 4,
-                           A + (size_t)(k0 + nb) * lda + k0 + nb, lda, n_right, nrt >> 4,
-                           Bm + (size_t)(k0 + nb) * ldb, ldb, nr, nbp >> 4, nrt, n_right);
+                           (double*)(A + (size_t)(k0 + nb) * lda + k0 + nb), lda, n_right, nrt >> 4,
+                           (double*)(Bm + (size_t)(k0 + nb) * ldb), ldb, nr, nbp >> 4, nrt, n_right);
         __syncthreads();
         RK_STAMP(4);
+    }
+    if (n > 64 && n <= 16 * BS_T && nr <= 16 * BS_T && DT == 512) {     // right-hand side resident in registers
+        lu_backsub_regs((const double*)A, lda, (double*)Bm, ldb, n, nr);
+        RK_STAMP(5);
+        return;
     }
     // back substitution with U, block rows from the bottom
     for (int k0 = ((n - 1) / LU_NB) * LU_NB; k0 >= 0; k0 -= LU_NB) {
@@ -645,7 +768,7 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         lu_trsm_upper(Bm + (size_t)k0 * ldb, ldb, k0, nb, nr, nbp, lds + us_off, usp);
         __syncthreads();
         RK_STAMP(5);
-        if (k0 > 0) lu_rank_update(0, k0, nb, us_off, usp, k0 >> 4, Bm, ldb, 0, 0, Bm, ldb, nr, nbp >> 4, 0, k0);
+        if (k0 > 0) lu_rank_update(0, k0, nb, us_off, usp, k0 >> 4, (double*)Bm, ldb, 0, 0, (double*)Bm, ldb, nr, nbp >> 4, 0, k0);
         __syncthreads();
         RK_STAMP(6);
     }
@@ -679,10 +802,10 @@ size_t dense_ws_doubles(int p, int m) {
 // C1 = Q X (rows of X), and, if X2T: C2 = Q X2T^T (X2T read transposed: the T^T = Q Sigma_f^T of standard.py:175)
 __device__ __noinline__ void wg_bd_left(double* C1_, const double* X_, double* C2_, const double* X2T_, int p_, int nd_) {
     const double* const qd = g_qd;
-    double* const C1 = uni(C1_);
-    const double* const X = uni(X_);
-    double* const C2 = uni(C2_);
-    const double* const X2T = uni(X2T_);
+    auto* const C1 = uni_g(C1_);
+    auto* const X = uni_g(X_);
+    auto* const C2 = uni_g(C2_);
+    auto* const X2T = uni_g(X2T_);
     const int p = uni(p_), nd = uni(nd_);
     const int nblk = p / nd, total = nblk * p;
     constexpr int U = 2;                                   // items per pass: all their loads are issued before the arithmetic
@@ -720,11 +843,11 @@ __device__ __noinline__ void wg_bd_left(double* C1_, const double* X_, double* C
 // C = X Q^T + E ; and, if D: D = F - C   (the Sigma_next - Sigma^- of standard.py:215 in the same pass)
 __device__ __noinline__ void wg_bd_right(double* C_, const double* X_, const double* E_, double* D_, const double* F_, int p_, int nd_) {
     const double* const qd = g_qd;
-    double* const C = uni(C_);
-    const double* const X = uni(X_);
-    const double* const E = uni(E_);
-    double* const D = uni(D_);
-    const double* const F = uni(F_);
+    auto* const C = uni_g(C_);
+    auto* const X = uni_g(X_);
+    auto* const E = uni_g(E_);
+    auto* const D = uni_g(D_);
+    auto* const F = uni_g(F_);
     const int p = uni(p_), nd = uni(nd_);
     const int nblk = p / nd, total = nblk * p;
     constexpr int U = 2;
