@@ -386,9 +386,12 @@ __device__ __forceinline__ void lu_panel_col(double (&a)[RS][LU_NB], int (&pos)[
     if (l == 0) g_ppiv[J] = pj;
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
-        if (pos[s] == pj) {                                 // the pivot row's owner publishes it
+        const bool mine = pos[s] == pj;
+        if (__builtin_amdgcn_ballot_w64(mine) != 0) {       // (uniform: only the slot that holds the pivot row issues the writes)
+            if (mine) {                                     // the pivot row's owner publishes it
 #pragma unroll
-            for (int c = 0; c < LU_NB; ++c) buf[c] = a[s][c];
+                for (int c = 0; c < LU_NB; ++c) buf[c] = a[s][c];
+            }
         }
     }
 #pragma unroll
@@ -398,7 +401,7 @@ __device__ __forceinline__ void lu_panel_col(double (&a)[RS][LU_NB], int (&pos)[
 #pragma unroll
     for (int c = J; c < LU_NB; ++c) prow[c] = buf[c];
     wave_lds_sync();                                        // the buffer is free for the next column
-    const double rinv = 1.0 / prow[J];
+    const double rinv = fast_rcp(prow[J]);                  // <= 1 ulp from 1 / pivot (linalg_small.hpp), six operations
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
         if (pos[s] > J && pos[s] != 0x7fffffff) {
