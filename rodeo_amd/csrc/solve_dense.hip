@@ -523,14 +523,18 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
 // per column loads the (at most 32) moved rows of its column and stores them to their new places -- no barrier, no
 // thread touches another thread's column.  Row bases are uniform (scalar), the column is the per-thread offset.
 __device__ __forceinline__ void lu_swap_cols(gd* M, int ld, int ncols, int nm) {
+    // the moved rows' destinations and sources: read once per wave (lane li holds entry li), handed out by readlane
+    const int l = threadIdx.x & 63;
+    const int my_dst = l < nm ? g_mlist[l] : 0;
+    const int my_src = l < nm ? g_cur[my_dst] : 0;
     for (int cc = threadIdx.x; cc < ncols; cc += DT) {
         double tmp[2 * LU_NB];
 #pragma unroll
         for (int li = 0; li < 2 * LU_NB; ++li)
-            if (li < nm) tmp[li] = (M + uni(g_cur[g_mlist[li]]) * ld)[cc];
+            if (li < nm) tmp[li] = (M + __builtin_amdgcn_readlane(my_src, li) * ld)[cc];
 #pragma unroll
         for (int li = 0; li < 2 * LU_NB; ++li)
-            if (li < nm) (M + uni(g_mlist[li]) * ld)[cc] = tmp[li];
+            if (li < nm) (M + __builtin_amdgcn_readlane(my_dst, li) * ld)[cc] = tmp[li];
     }
 }
 
