@@ -77,7 +77,7 @@ class SolvePlan:
             from .trace import from_python
             skip = {"kalman_type"}
             sizes = {k: int(np.shape(v)[-1]) if np.ndim(v) >= 1 else 1 for k, v in params.items() if k not in skip}
-            ode_fun = from_python(ode_fun, int(np.shape(ode_weight)[-3]), min(2, int(np.shape(ode_weight)[-1])), **sizes)
+            ode_fun = from_python(ode_fun, int(np.shape(ode_weight)[-3]), int(np.shape(ode_weight)[-1]), **sizes)
         self.dev = device if device is not None else default_device()
         self._ode_fun = ode_fun
         itg_id, bound = _interrogate_id(interrogate)

@@ -399,3 +399,23 @@ def test_traced_twelve_variable_system(ra, p):
     mo = np.stack([scan.solve_mv(None, o, W, x0[b], 0.0, t_max, N, oi.interrogate_kramer, prior, kc=kc[b])[0] for b in range(B)])
     sm = np.max(np.abs(mo), axis=(0, 1, 2))
     assert m.shape == mo.shape and np.max(np.abs(m - mo) / sm) < 1e-8
+
+
+def test_traced_function_reading_a_derivative(ra):
+    """A right-hand side that reads the first derivative too (damped oscillator x'' = -x - c x' with the second-order
+    weight): NDEP = 2, so the lane-per-trajectory kernels; traced automatically by solve_mv."""
+    def damped(X, t, **params):
+        c = params["c"]
+        return np.array([[-X[0, 0] - c[0] * X[0, 1]]])
+    W = np.array([[[0., 0., 1., 0.]]])
+    x0 = np.array([[1., 0., -1., 0.3]])
+    c = np.array([0.3])
+    N, t_max = 100, 5.0
+    prior = ra.ibm_init(t_max / N, 4, np.array([.01]))
+    m, v = ra.solve_mv(None, damped, W, x0, 0., t_max, N, ra.interrogate.interrogate_kramer, prior, c=c)
+    mo, vo = scan.solve_mv(None, _oracle_ode("damped", damped, 1), W, x0, 0., t_max, N, oi.interrogate_kramer, prior, c=c)
+    assert np.max(np.abs(m - mo)) < 1e-9 and np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))
+    w = np.sqrt(1 - 0.15 ** 2)
+    t = np.linspace(0, t_max, N + 1)
+    exact = np.exp(-0.15 * t) * (np.cos(w * t) + 0.15 / w * np.sin(w * t))
+    assert np.max(np.abs(m[:, 0, 0] - exact)) < 5e-3
