@@ -209,6 +209,16 @@ def main():
                                "frac": (a_fwd + a_bwd) * units / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_traj_step": a_fwd + a_bwd},
         }
+        # why the dominant kernel sits far below the HBM roof: one dependent chain per wave
+        fwd = next((k for k in kern_ms if k.startswith("fwd")), None)
+        if fwd is not None:
+            tiles_per_wave = 4
+            out["latency_bound"] = {
+                "kernel": fwd, "ns_per_dependent_step": kern_ms[fwd] * 1e6 / N_STEPS,
+                "waves": -(-N_TRAJ * D // tiles_per_wave), "simds": 1024,
+                "note": "the filter recursion is sequential in time: one wave per SIMD at most, its time is n_steps x the "
+                        "step's dependent instruction chain (7 fp64 MFMAs + 13 VALU ~ 240 cycles) whatever the batch up to "
+                        "2048 trajectories (profiles/r01_c2_kernel_times_vs_batch.log)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, x0, theta, prior)
         print(json.dumps(out), flush=True)
