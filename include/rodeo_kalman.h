@@ -200,6 +200,15 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* 
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
                        int32_t n_obs, double* logdens);
 
+/* Fenrir's data-adaptive solver (src/rodeo/inference/fenrir.py:333-457 `_smooth_mv`, `solve_mv`): mean and variance of
+ * p(X_{0:N} | Z_{1:N}, Y_{0:M}).  Input as for rk_fenrir_backward with RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR; the
+ * backward filter's moments are kept in `workspace` (rk_fenrir_workspace_bytes), the smoothing pass overwrites
+ * out->mean_state / out->var_state (batch-minor (N+1, d, p [,p], B)) with the result.                              */
+int rk_fenrir_workspace_bytes(const rk_solve_cfg* cfg, size_t* bytes);
+int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
+                       const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
+                       int32_t n_obs, void* workspace);
+
 /* ---- per-step operator boundary -------------------------------------------------------------------------
  * Batched versions of the nine functions of src/rodeo/kalmantv/standard.py (kalman_type = RK_KALMAN_STANDARD)
  * and src/rodeo/kalmantv/square_root.py (RK_KALMAN_SQRT).  n = batch size (the reference's vmap axis);

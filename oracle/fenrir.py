@@ -1,6 +1,7 @@
 """
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Restatement of the Fenrir log-likelihood
-(src/rodeo/inference/fenrir.py:40-81 ``_forecast_update``, :86-259 ``_backward``, :261-327 ``fenrir``) and of the
+(src/rodeo/inference/fenrir.py:40-81 ``_forecast_update``, :86-259 ``_backward``, :261-327 ``fenrir``, :333-457 ``_smooth_mv`` /
+``solve_mv``) and of the
 eigendecomposition log-density it uses (src/rodeo/utils.py:60-78), for one trajectory or a leading batch axis.
 
 The reference's tests do not cover fenrir (tests/ holds nothing for it), so this restatement is pinned by what the
@@ -33,8 +34,10 @@ def _forecast_update(mean_state_pred, var_state_pred, x_meas, mean_meas, wgt_mea
 
 
 def backward(mean_state_filt, var_state_filt, mean_state_pred, var_state_pred, prior_weight, prior_var,
-             t_min, t_max, n_steps, obs_data, obs_times, obs_weight, obs_var):
-    """fenrir.py:86-259 for one trajectory: arrays (N+1, d, p[, p]); returns the log-density."""
+             t_min, t_max, n_steps, obs_data, obs_times, obs_weight, obs_var, return_states=False):
+    """fenrir.py:86-259 for one trajectory: arrays (N+1, d, p[, p]); returns the log-density (and, on request, the
+    ``state_par`` dictionary of fenrir.py:236-258: backward-filter predictions / updates for n = 0..N, Markov weights and
+    variances for n = 0..N-1)."""
     n_obs, n_block, n_bobs, n_bstate = np.shape(obs_weight)
     sim_times = np.linspace(t_min, t_max, n_steps + 1)
     obs_ind = np.searchsorted(sim_times, obs_times)
@@ -42,10 +45,16 @@ def backward(mean_state_filt, var_state_filt, mean_state_pred, var_state_pred, p
     i = n_obs - 1
     logdens = 0.0
     bmean, bvar = mean_state_filt[n_steps], var_state_filt[n_steps]
+    N1 = n_steps + 1
+    pm, pv = np.zeros(np.shape(mean_state_filt)), np.zeros(np.shape(var_state_filt))        # backward predictions
+    fm, fv = np.zeros(np.shape(mean_state_filt)), np.zeros(np.shape(var_state_filt))        # backward updates
+    wA, wC = np.zeros((n_steps,) + np.shape(var_state_filt)[1:]), np.zeros((n_steps,) + np.shape(var_state_filt)[1:])
+    pm[n_steps], pv[n_steps] = bmean, bvar                                    # fenrir.py:226-232: the terminal point
     if obs_ind[i] >= n_steps:                                                 # fenrir.py:189-209
         logp, bmean, bvar = _forecast_update(bmean, bvar, obs_data[i], obs_mean, obs_weight[i], obs_var[i])
         logdens += logp
         i -= 1
+    fm[n_steps], fv[n_steps] = bmean, bvar                                    # fenrir.py:233-238
     for t in range(n_steps - 1, -1, -1):                                       # reverse scan, fenrir.py:131-184, 217-222
         A, b, C = kalman_ops.smooth_cond(mean_state_filt=mean_state_filt[t], var_state_filt=var_state_filt[t],
                                          mean_state_pred=mean_state_pred[t + 1], var_state_pred=var_state_pred[t + 1],
@@ -57,7 +66,41 @@ def backward(mean_state_filt, var_state_filt, mean_state_pred, var_state_pred, p
             i -= 1
         else:
             bmean, bvar = bmp, bvp
+        pm[t], pv[t], fm[t], fv[t], wA[t], wC[t] = bmp, bvp, bmean, bvar, A, C
+    if return_states:
+        return logdens, {"state_pred": (pm, pv), "state_filt": (fm, fv), "wgt_state": wA, "var_state": wC}
+    assert N1 == len(pm)
     return logdens
+
+
+def _smooth_mv(state_par):
+    """fenrir.py:333-402: the smoothing pass over the backward filter (a forward sweep in time; x_0 and x_1 keep the
+    backward filter's own estimates, which already condition on all the data)."""
+    (pm, pv), (fm, fv) = state_par["state_pred"], state_par["state_filt"]
+    wA, wC = state_par["wgt_state"], state_par["var_state"]
+    n_tot = pm.shape[0]
+    sm, sv = fm.copy(), fv.copy()
+    cm, cv = fm[1], fv[1]                                                      # scan_init, fenrir.py:379-382
+    for k in range(n_tot - 2):                                                 # filt[2:], pred[1:n_tot-1], wgt/var_state[1:n_tot]
+        cm, cv = kalman_ops.smooth_mv(mean_state_next=cm, var_state_next=cv, wgt_state=wA[k + 1],
+                                      mean_state_filt=fm[k + 2], var_state_filt=fv[k + 2],
+                                      mean_state_pred=pm[k + 1], var_state_pred=pv[k + 1], var_state=wC[k + 1])
+        sm[k + 2], sv[k + 2] = cm, cv
+    return sm, sv
+
+
+def solve_mv(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars,
+             obs_data, obs_times, obs_weight, obs_var, kalman_type="standard", **params):
+    """fenrir.py:405-457 for one trajectory: mean and variance of p(X_{0:N} | Z_{1:N}, Y_{0:M})."""
+    if kalman_type != "standard":
+        raise NotImplementedError
+    prior_weight, prior_var = prior_pars
+    filt = scan.solve_filter(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate,
+                             prior_weight, prior_var, **params)
+    (mp, vp), (mf, vf) = filt["state_pred"], filt["state_filt"]
+    _, state_par = backward(mf, vf, mp, vp, np.asarray(prior_weight, dtype=float), np.asarray(prior_var, dtype=float),
+                            t_min, t_max, n_steps, obs_data, obs_times, obs_weight, obs_var, return_states=True)
+    return _smooth_mv(state_par)
 
 
 def fenrir(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars,

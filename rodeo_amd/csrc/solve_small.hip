@@ -156,11 +156,14 @@ __global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile,
 // (batch-minor filt and pred), conditioning on the observations y_i = D_i X_{n(i)} + N(0, Omega_i) at their grid
 // indices; every observation contributes log N(y_i; D m, D S D^T + Omega) with utils.py:60-78's rule that a variance
 // with |w| <= 1e-8 contributes nothing (jnp.isclose(w, 0, rtol=1e-300)).  Block values are summed per trajectory.
-template <int P>
+// With STORE (fenrir.py:236-258, for fenrir's solve_mv) the backward filter's predicted and updated moments of every
+// time and the Markov weights A_n are kept in `states`: per (time n, block) an item of 3 P^2 + 2 P doubles
+// [m_pred (P), S_pred (P^2), m_filt (P), S_filt (P^2), A (P^2)], batch-minor.
+template <int P, bool STORE>
 __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const double* __restrict__ obs,
                                                         const double* __restrict__ obs_w, const double* __restrict__ obs_v,
                                                         const int32_t* __restrict__ obs_ind, int n_obs,
-                                                        double* __restrict__ logdens) {
+                                                        double* __restrict__ logdens, double* __restrict__ states) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= a.B * a.D) return;
     const int blk = l / a.B, b = l - blk * a.B;
@@ -201,7 +204,19 @@ __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const doubl
         }
         --i;
     };
+    constexpr int ITEM = 3 * P * P + 2 * P;
+    auto keep = [&](int n, int off, const double (&m)[P], const double (&S)[P][P]) {
+        double* o = states + (((size_t)n * a.D + blk) * ITEM + off) * B + b;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            o[(size_t)r * B] = m[r];
+#pragma unroll
+            for (int c = 0; c < P; ++c) o[(size_t)(P + r * P + c) * B] = S[r][c];
+        }
+    };
+    if constexpr (STORE) keep(a.N, 0, bm, bS);                              // "prediction" at N = the terminal point
     if (i >= 0 && obs_ind[i] >= a.N) observe(bm, bS);                      // fenrir.py:189-209
+    if constexpr (STORE) keep(a.N, P + P * P, bm, bS);
     for (int n = a.N - 1; n >= 0; --n) {
         double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P], G[P][P];
         load_filt<P>(a, n, blk, b, mf, Sf);
@@ -232,9 +247,85 @@ __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const doubl
 #pragma unroll
             for (int c = 0; c < P; ++c) bS[r][c] = nS[r][c];
         }
+        if constexpr (STORE) {
+            keep(n, 0, bm, bS);
+            double* o = states + (((size_t)n * a.D + blk) * ITEM + 2 * (P + P * P)) * B + b;
+#pragma unroll
+            for (int r = 0; r < P; ++r)
+#pragma unroll
+                for (int c = 0; c < P; ++c) o[(size_t)(r * P + c) * B] = G[r][c];
+        }
         if (i >= 0 && obs_ind[i] == n) observe(bm, bS);                     // fenrir.py:155-170
+        if constexpr (STORE) keep(n, P + P * P, bm, bS);
     }
-    atomicAdd(&logdens[b], acc);
+    if (logdens) atomicAdd(&logdens[b], acc);
+}
+
+// fenrir.py:333-402: the smoothing pass over the backward filter's stored moments, a forward sweep in time -- times 0 and
+// 1 keep the backward filter's own estimates; for k = 0 .. N-2
+//     (m, S)_{k+2} = smooth_mv(next = (m, S)_{k+1}, wgt_state = A_{k+1}, filt = bfilt_{k+2}, pred = bpred_{k+1}).
+// Results go to a.mean / a.var (batch-minor), which the backward filter no longer needs.
+template <int P>
+__global__ void __launch_bounds__(64) fenrir_smooth_kernel(SolveArgs a, const double* __restrict__ states) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.B * a.D) return;
+    const int blk = l / a.B, b = l - blk * a.B;
+    const size_t B = (size_t)a.B;
+    constexpr int ITEM = 3 * P * P + 2 * P;
+    auto item = [&](int n, int off, double (&m)[P], double (&S)[P][P]) {
+        const double* o = states + (((size_t)n * a.D + blk) * ITEM + off) * B + b;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            m[r] = o[(size_t)r * B];
+#pragma unroll
+            for (int c = 0; c < P; ++c) S[r][c] = o[(size_t)(P + r * P + c) * B];
+        }
+    };
+    auto put = [&](int n, const double (&m)[P], const double (&S)[P][P]) {
+        double* mo = a.mean + ((size_t)n * a.D + blk) * P * B + b;
+        double* vo = a.var + ((size_t)n * a.D + blk) * P * P * B + b;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            mo[(size_t)r * B] = m[r];
+#pragma unroll
+            for (int c = 0; c < P; ++c) vo[((size_t)r * P + c) * B] = S[r][c];
+        }
+    };
+    double cm[P], cS[P][P];
+    item(0, P + P * P, cm, cS);
+    put(0, cm, cS);
+    if (a.N < 1) return;
+    item(1, P + P * P, cm, cS);
+    put(1, cm, cS);
+    for (int k = 0; k + 2 <= a.N; ++k) {
+        double fm[P], fS[P][P], pm[P], pS[P][P], A[P][P], T[P][P], G[P][P];
+        item(k + 2, P + P * P, fm, fS);
+        item(k + 1, 0, pm, pS);
+        {
+            const double* o = states + (((size_t)(k + 1) * a.D + blk) * ITEM + 2 * (P + P * P)) * B + b;
+#pragma unroll
+            for (int r = 0; r < P; ++r)
+#pragma unroll
+                for (int c = 0; c < P; ++c) A[r][c] = o[(size_t)(r * P + c) * B];
+        }
+        smooth_gain<P>(A, fS, pS, T, G);                                    // standard.py:175-176 with wgt_state = A
+        double dm[P], dS[P][P], GD[P][P], nS[P][P];
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            dm[r] = cm[r] - pm[r];
+#pragma unroll
+            for (int c = 0; c < P; ++c) dS[r][c] = cS[r][c] - pS[r][c];
+        }
+        mm<P, P, P>(G, dS, GD);
+        mm_nt<P, P, P>(GD, G, nS);
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            cm[r] = fm[r] + dot<P>(G[r], dm);                               // standard.py:213-214
+#pragma unroll
+            for (int c = 0; c < P; ++c) cS[r][c] = fS[r][c] + nS[r][c];     // standard.py:215-216
+        }
+        put(k + 2, cm, cS);
+    }
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------------------------
@@ -568,11 +659,61 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
     const dim3 grid(div_up(a.B * a.D, 64)), block(64);
     LaunchTimer t(h, "fenrir_bwd_kernel");
     switch (c->n_bstate) {
-        case 2: hipLaunchKernelGGL(fenrir_bwd_kernel<2>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
-        case 3: hipLaunchKernelGGL(fenrir_bwd_kernel<3>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
-        case 4: hipLaunchKernelGGL(fenrir_bwd_kernel<4>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
-        case 5: hipLaunchKernelGGL(fenrir_bwd_kernel<5>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
-        default: hipLaunchKernelGGL(fenrir_bwd_kernel<6>, grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens); break;
+        case 2: hipLaunchKernelGGL((fenrir_bwd_kernel<2, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
+        case 3: hipLaunchKernelGGL((fenrir_bwd_kernel<3, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
+        case 4: hipLaunchKernelGGL((fenrir_bwd_kernel<4, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
+        case 5: hipLaunchKernelGGL((fenrir_bwd_kernel<5, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
+        default: hipLaunchKernelGGL((fenrir_bwd_kernel<6, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
+    }
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+int rk_fenrir_workspace_bytes(const rk_solve_cfg* c, size_t* bytes) {
+    RK_REQUIRE(c && bytes, RK_ERR_INVALID, "rk_fenrir_workspace_bytes: null argument");
+    const size_t p = (size_t)c->n_bstate;
+    *bytes = sizeof(double) * (size_t)(c->n_steps + 1) * c->n_block * (3 * p * p + 2 * p) * c->n_traj;
+    return RK_OK;
+}
+
+int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out,
+                       const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
+                       int32_t n_obs, void* workspace) {
+    RK_REQUIRE(h && c && in && out && obs && obs_weight && obs_var && obs_ind && workspace, RK_ERR_INVALID,
+               "rk_fenrir_solve_mv: null argument");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_solve_mv: kalman_type must be standard");
+    RK_REQUIRE((c->flags & RK_FLAG_STORE_PRED) && (c->flags & RK_FLAG_BATCH_MINOR) && out->mean_state && out->var_state &&
+               out->mean_pred && out->var_pred, RK_ERR_INVALID,
+               "rk_fenrir_solve_mv needs the batch-minor filtered AND predicted moments of rk_solve_filter "
+               "(RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)");
+    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6 && n_obs >= 0, RK_ERR_UNSUPPORTED,
+               "rk_fenrir_solve_mv: n_bstate in 2..6, scalar observations per block");
+    SolveArgs a;
+    int rc = make_args(c, in, out, a);
+    if (rc) return rc;
+    RK_HIP(hipSetDevice(h->device));
+    const dim3 grid(div_up(a.B * a.D, 64)), block(64);
+    double* st = (double*)workspace;
+    {
+        LaunchTimer t(h, "fenrir_bwd_kernel");
+        switch (c->n_bstate) {
+            case 2: hipLaunchKernelGGL((fenrir_bwd_kernel<2, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
+            case 3: hipLaunchKernelGGL((fenrir_bwd_kernel<3, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
+            case 4: hipLaunchKernelGGL((fenrir_bwd_kernel<4, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
+            case 5: hipLaunchKernelGGL((fenrir_bwd_kernel<5, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
+            default: hipLaunchKernelGGL((fenrir_bwd_kernel<6, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
+        }
+        t.stop();
+    }
+    RK_HIP(hipGetLastError());
+    LaunchTimer t(h, "fenrir_smooth_kernel");
+    switch (c->n_bstate) {
+        case 2: hipLaunchKernelGGL(fenrir_smooth_kernel<2>, grid, block, 0, h->stream, a, st); break;
+        case 3: hipLaunchKernelGGL(fenrir_smooth_kernel<3>, grid, block, 0, h->stream, a, st); break;
+        case 4: hipLaunchKernelGGL(fenrir_smooth_kernel<4>, grid, block, 0, h->stream, a, st); break;
+        case 5: hipLaunchKernelGGL(fenrir_smooth_kernel<5>, grid, block, 0, h->stream, a, st); break;
+        default: hipLaunchKernelGGL(fenrir_smooth_kernel<6>, grid, block, 0, h->stream, a, st); break;
     }
     t.stop();
     RK_HIP(hipGetLastError());

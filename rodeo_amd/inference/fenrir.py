@@ -63,3 +63,42 @@ def _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate,
     if lay.value != _lib.LAYOUT_TILE3:
         plan = cached_plan(*args, store_pred=True, batch_minor=True, **params)
     return plan
+
+
+def solve_mv(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars,
+             obs_data, obs_times, obs_weight, obs_var, kalman_type="standard", **params):
+    """
+    Fenrir's data-adaptive solver (src/rodeo/inference/fenrir.py:405-457): mean and variance of
+    p(X_{0:N} | Z_{1:N}, Y_{0:M}) -- forward filter, backward filter through the observations, smoothing pass over the
+    backward filter (``_smooth_mv``, fenrir.py:333-402).  Same arguments as ``fenrir``; returns ``(mean (N+1, d, p), var
+    (N+1, d, p, p))`` with a leading batch axis for batched inputs.  Lane-per-trajectory kernels (``rk_fenrir_solve_mv``).
+    """
+    if kalman_type not in ("standard", "square-root"):
+        raise NotImplementedError                                   # fenrir.py:421-426
+    if kalman_type != "standard":
+        raise NotImplementedError("fenrir.solve_mv on the device: kalman_type='standard' only in this build")
+    obs = np.asarray(obs_data, dtype=np.float64)
+    D = np.asarray(obs_weight, dtype=np.float64)
+    Om = np.asarray(obs_var, dtype=np.float64)
+    if D.ndim != 4 or D.shape[2] != 1 or Om.shape != D.shape[:2] + (1, 1) or obs.shape != D.shape[:2] + (1,):
+        raise ValueError("fenrir: obs_data (n_obs, n_block, 1), obs_weight (n_obs, n_block, 1, n_bstate), obs_var "
+                         "(n_obs, n_block, 1, 1) -- scalar observations per block in this build")
+    ind = obs_index(t_min, t_max, n_steps, obs_times)
+    if np.any(np.diff(ind) < 0):
+        raise ValueError("obs_times must be ascending")
+    from ..solve import SolvePlan
+    plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
+                     store_pred=True, batch_minor=True, **params)
+    if D.shape[1:] != (plan.d, 1, plan.p):
+        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, 1, {plan.p})")
+    plan.filter(key)
+    dev = plan.dev
+    d_obs, d_w, d_v, d_ind = (dev.to_device(np.ascontiguousarray(a)) for a in
+                              (obs[:, :, 0], D[:, :, 0, :], Om[:, :, 0, 0], ind.astype(np.int32)))
+    nbytes = C.c_size_t(0)
+    _lib.check(dev.lib.rk_fenrir_workspace_bytes(C.byref(plan.cfg), C.byref(nbytes)))
+    ws = dev.empty((nbytes.value // 8,))
+    _lib.check(dev.lib.rk_fenrir_solve_mv(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(plan._out), d_obs.ptr,
+                                          d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), ws.ptr))
+    return plan.state_host()
+

@@ -291,3 +291,38 @@ def test_fenrir_lorenz_three_blocks(ra):
     for fun in (ra.ode.lorenz63, lorenz):
         val = ra.inference.fenrir(None, fun, *args, ra.interrogate.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
         np.testing.assert_allclose(val, ref, rtol=1e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize("p", [3, 4])
+def test_fenrir_solve_mv_parity(ra, p):
+    """inference.fenrir.solve_mv (fenrir.py:405-457, the data-adaptive solver of docs/examples/lorenz.md) against the oracle
+    restatement (itself pinned by the exact Gaussian posterior of a linear model): single trajectory and a batch,
+    observations at both ends and in between."""
+    from oracle import fenrir as ofen
+    from rodeo_amd.inference.fenrir import solve_mv as fsolve            # as docs/examples/lorenz.md:39 imports it
+    N, t_max, B = 60, 3.0, 4
+    rng = np.random.default_rng(21)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0 = init(np.array([-1., 1.]) + 0.05 * rng.standard_normal((B, 2)), 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / N, p, np.array([.1, .1]))
+    obs_times = np.array([0.0, 0.75, 1.5, 2.25, 3.0])
+    n_obs = len(obs_times)
+    y = np.array([-1., 1.])[None, :, None] + 0.3 * rng.standard_normal((n_obs, 2, 1))
+    Dw = np.zeros((n_obs, 2, 1, p)); Dw[..., 0] = 1.0
+    Om = np.full((n_obs, 2, 1, 1), 0.02)
+    m, v = fsolve(None, ra.ode.fitzhugh_nagumo, W, x0, 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior,
+                         y, obs_times, Dw, Om, theta=theta)
+    assert m.shape == (B, N + 1, 2, p) and v.shape == (B, N + 1, 2, p, p)
+    for b in range(B):
+        mo, vo = ofen.solve_mv(None, odes.fitzhugh_nagumo, W, x0[b], 0.0, t_max, N, oi.interrogate_kramer, prior, y,
+                               obs_times, Dw, Om, theta=theta[b])
+        assert np.max(np.abs(m[b] - mo)) < 1e-8 * max(1.0, np.max(np.abs(mo)))
+        assert np.max(np.abs(v[b] - vo)) < 1e-7 * np.max(np.abs(vo))
+    m1, v1 = fsolve(None, ra.ode.fitzhugh_nagumo, W, x0[0], 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior,
+                           y, obs_times, Dw, Om, theta=theta[0])
+    assert m1.shape == (N + 1, 2, p) and np.max(np.abs(m1 - m[0])) < 1e-12
+    # the observations pull the solution: at an observed time the posterior mean sits between solver and data
+    m0, _ = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, W, x0[0], 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior,
+                        theta=theta[0])
+    assert np.max(np.abs(m1 - m0)) > 1e-9

@@ -70,3 +70,54 @@ def test_logpdf_drops_null_directions():
     val = ofen.multivariate_normal_logpdf(x, m, cov)
     ref = multivariate_normal.logpdf([1.0, -1.0], [0, 0], np.diag([2.0, 0.5]))
     assert abs(val - ref) < 1e-12
+
+
+def _exact_posterior(W, x0, Q, R, N, t_min, t_max, forcing, obs_ind, D, Om, y):
+    """Mean and marginal covariances of X_1..X_N given z_{1:N} = 0 AND the observations (same model as _exact_loglik)."""
+    p = len(x0)
+    mean = np.zeros((N + 1, p)); mean[0] = x0
+    cov = np.zeros((N + 1, N + 1, p, p))
+    for n in range(1, N + 1):
+        mean[n] = Q @ mean[n - 1]
+        cov[n, n] = Q @ cov[n - 1, n - 1] @ Q.T + R
+        for k in range(n):
+            cov[n, k] = Q @ cov[n - 1, k]
+            cov[k, n] = cov[n, k].T
+    mu = mean[1:].reshape(-1)
+    S = np.block([[cov[i, j] for j in range(1, N + 1)] for i in range(1, N + 1)])
+    ts = t_min + (t_max - t_min) * np.arange(1, N + 1) / N
+    H = np.zeros((N + len(obs_ind), N * p)); rhs = np.zeros(N + len(obs_ind)); noise = np.zeros(N + len(obs_ind))
+    for n in range(N):
+        H[n, n * p:(n + 1) * p] = W - forcing["a"]
+        rhs[n] = forcing["f"](ts[n])
+    for m, n in enumerate(obs_ind):
+        H[N + m, (n - 1) * p:n * p] = D
+        rhs[N + m] = y[m]; noise[N + m] = Om
+    Sh = H @ S @ H.T + np.diag(noise)
+    K = S @ H.T @ np.linalg.pinv(Sh, hermitian=True)
+    mu_c = mu + K @ (rhs - H @ mu)
+    S_c = S - K @ H @ S
+    return mu_c.reshape(N, p), np.stack([S_c[n * p:(n + 1) * p, n * p:(n + 1) * p] for n in range(N)])
+
+
+def test_fenrir_solve_mv_equals_exact_gaussian_posterior_for_a_linear_ode():
+    """oracle/fenrir.solve_mv (fenrir.py:333-457) against the exact posterior p(X_n | z_{1:N} = 0, y) of the same model."""
+    N, t_min, t_max, p = 10, 0.0, 1.0, 3
+    W = np.array([[[0.0, 0.0, 1.0]]])
+    x0 = np.array([[-1.0, 0.0, 1.0]])
+    Q, R = priors.ibm_init((t_max - t_min) / N, p, np.array([0.5]))
+    obs_times = np.array([0.2, 0.5, 1.0])
+    obs_ind = np.searchsorted(np.linspace(t_min, t_max, N + 1), obs_times)
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((3, 1, 1)) * 0.3 - 0.5
+    D = np.array([1.0, 0.0, 0.0])
+    obs_weight = np.tile(D[None, None, None, :], (3, 1, 1, 1))
+    Om = 0.05
+    obs_var = np.full((3, 1, 1, 1), Om)
+    m, v = ofen.solve_mv(None, odes.higher_order, W, x0, t_min, t_max, N, oi.interrogate_kramer, (Q, R), y, obs_times,
+                         obs_weight, obs_var)
+    assert m.shape == (N + 1, 1, p) and v.shape == (N + 1, 1, p, p)
+    me, ve = _exact_posterior(W[0, 0], x0[0], Q[0], R[0], N, t_min, t_max,
+                              {"a": np.array([-1.0, 0.0, 0.0]), "f": lambda t: np.sin(2 * t)}, obs_ind, D, Om, y[:, 0, 0])
+    np.testing.assert_allclose(m[0, 0], x0[0]); assert np.all(v[0] == 0)
+    assert np.max(np.abs(m[1:, 0] - me)) < 1e-8 and np.max(np.abs(v[1:, 0] - ve)) < 1e-8
