@@ -326,3 +326,16 @@ def test_fenrir_solve_mv_parity(ra, p):
     m0, _ = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, W, x0[0], 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior,
                         theta=theta[0])
     assert np.max(np.abs(m1 - m0)) > 1e-9
+
+
+def test_lorenz_md_example_with_fenrir_solver():
+    """examples/lorenz_fenrir.py = docs/examples/lorenz.md (its Python lorenz function, settings and data): the data-free
+    solver is accurate early and has left the chaotic trajectory by t = 10; the Fenrir solver passes through the
+    observations (the document's own conclusion: only dalton recovers the truth in between)."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "lorenz_fenrir.py")
+    spec = importlib.util.spec_from_file_location("lorenz_fenrir", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    err_early, at_obs_r, at_obs_f = mod.main()
+    assert err_early < 3.0 and at_obs_r > 5.0 and at_obs_f < 0.05
