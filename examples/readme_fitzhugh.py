@@ -16,7 +16,7 @@ import rodeo_amd as rodeo
 
 
 def fitz_fun(X, t, **params):
-    "FitzHugh-Nagumo ODE in rodeo format."
+    # V' = c (V - V^3/3 + R),  R' = -(V - a + b R) / c;  X[:, 0] holds (V, R), the return value one row per variable
     a, b, c = params["theta"]
     V, R = X[:, 0]
     return np.array(
@@ -26,28 +26,25 @@ def fitz_fun(X, t, **params):
 
 
 def main():
-    n_vars = 2  # number of variables in the ODE
-    n_deriv = 3  # max number of derivatives
-    x0 = np.array([-1., 1.])  # initial value for the ODE-IVP
-    theta = np.array([.2, .2, 3])  # ODE parameters
+    n_vars, n_deriv = 2, 3
+    x0 = np.array([-1., 1.])
+    theta = np.array([.2, .2, 3])
     W, fitz_init_pad = rodeo.utils.first_order_pad(fitz_fun, n_vars, n_deriv)
-    X0 = fitz_init_pad(x0, 0., theta=theta)  # initial value in rodeo format
+    X0 = fitz_init_pad(x0, 0., theta=theta)          # (n_vars, n_deriv): [x0, f(x0), 0]
     t_min, t_max = 0., 40.
-    sigma = np.array([.1] * n_vars)  # IBM process scale factor
-    n_steps = 800  # number of evaluations steps
-    dt = (t_max - t_min) / n_steps  # step size
+    sigma = np.array([.1] * n_vars)
+    n_steps = 800
+    dt = (t_max - t_min) / n_steps
     prior_pars = rodeo.prior.ibm_init(dt=dt, n_deriv=n_deriv, sigma=sigma)
     key = 0
     Xt, _ = rodeo.solve_mv(
         key=key,
-        # define ode
-        ode_fun=fitz_fun,
+        ode_fun=fitz_fun,                  # the plain Python function above
         ode_weight=W,
         ode_init=X0,
         t_min=t_min,
         t_max=t_max,
-        theta=theta,  # ODE parameters added here
-        # solver parameters
+        theta=theta,
         n_steps=n_steps,
         interrogate=rodeo.interrogate.interrogate_kramer,
         prior_pars=prior_pars
