@@ -103,6 +103,7 @@ def main():
 
     dist = None
     comm = "none"
+    hard_exit = False
     if world > 1:
         sys.stdout.flush()
         saved_stdout = os.dup(1)
@@ -111,17 +112,45 @@ def main():
             import torch.distributed as dist
             dist.init_process_group("gloo", rank=rank, world_size=world)
             comm = "gloo"
-            try:
-                uid = (C.c_char * _lib.COMM_UID_BYTES)()
-                if rank == 0:
+            # RCCL communicator inside the library (only used for the barriers around the timed region: the data path has
+            # no collective).  Set up in a helper thread with a deadline, and used only if EVERY rank got it -- a rank
+            # stuck in the bootstrap must not take the scaling run down; gloo then carries the barriers.
+            import threading
+            import torch
+            state = {"ok": False, "err": None}
+
+            uid = (C.c_char * _lib.COMM_UID_BYTES)()
+            if rank == 0:
+                try:
                     _lib.check(lib.rk_comm_uid(uid))
-                box = [bytes(uid)]
-                dist.broadcast_object_list(box, src=0)
-                uid = (C.c_char * _lib.COMM_UID_BYTES).from_buffer_copy(box[0])
-                _lib.check(lib.rk_comm_init(dev.h, rank, world, uid))
+                except Exception as e:                       # noqa: BLE001
+                    state["err"] = e
+            box = [bytes(uid), state["err"] is None]
+            dist.broadcast_object_list(box, src=0)           # (gloo, main thread)
+            uid2 = (C.c_char * _lib.COMM_UID_BYTES).from_buffer_copy(box[0])
+
+            def _init():
+                try:
+                    _lib.check(lib.rk_comm_init(dev.h, rank, world, uid2))
+                    state["ok"] = True
+                except Exception as e:                       # noqa: BLE001
+                    state["err"] = e
+            stuck = False
+            if box[1]:
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("RK_BENCH_RCCL_TIMEOUT", "90")))
+                stuck = th.is_alive()
+            flag = torch.tensor([1 if (state["ok"] and not stuck) else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes part, stuck helper thread or not
+            if int(flag.item()) == 1:
                 comm = "rccl"
-            except Exception as e:
-                print(f"[rank {rank}] RCCL communicator unavailable ({e}); using gloo for barriers", file=sys.stderr)
+            else:
+                why = "timed out" if stuck else (state["err"] or "another rank failed")
+                print(f"[rank {rank}] RCCL communicator unavailable ({why}); using gloo for barriers", file=sys.stderr)
+                if state["ok"] and not stuck:
+                    lib.rk_comm_destroy(dev.h)
+                hard_exit = stuck
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -225,9 +254,12 @@ def main():
 
     if comm == "rccl":
         lib.rk_comm_destroy(dev.h)
-    if dist is not None:
+    if dist is not None and not hard_exit:
         dist.barrier()
         dist.destroy_process_group()
+    if hard_exit:                                    # a helper thread is still inside the RCCL bootstrap
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
