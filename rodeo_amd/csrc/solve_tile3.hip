@@ -52,8 +52,110 @@ __device__ __forceinline__ int lds_byte(int s, int g, int which, int idx) {
 // Workgroup = 4 waves for 4 tiles: wave 0 consumes, waves 1..3 produce; a workgroup's waves go to the CU's four SIMDs
 // one each, and the CU holds two or three such workgroups (48 KiB of LDS each) that run out of step with each
 // other, which evens out the load of the SIMDs (a speed consideration only -- any placement gives the same results).
-__global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D) {
+// The producer waves of the backward kernels (bwd_mv_tile3_kernel, fenrir_bwd_tile3_kernel): wave 1 + q owns the chunks
+// ch = q (mod 3) and hands [M-, G~^T, M_f] of every (step, tile) of a chunk over in LDS buffer ch & 1.
+__device__ __forceinline__ void tile3_gain_producers(const SolveArgs& a, const double* __restrict__ tiles, int D, int tw, int wave,
+                                                     int lane, int n_tiles, size_t tstride, int n_chunks, char* lds_raw,
+                                                     char* zones) {
     constexpr int P = 3;
+    // ---------------- producers: one lane per (step-in-chunk, tile) ----------------
+    const int p = wave - 1;
+    const int s = lane >> 2, g = lane & 3;
+    int tau = tw * 4 + g;
+    if (tau >= n_tiles) tau = n_tiles - 1;
+    const int b = tau / D, blk = tau - b * D;
+    double Q[P][P], R[P][P];
+    load_block_consts<P>(a, blk, b, Q, R);
+    int woff[12];                                              // LDS byte offsets of the 12 slots this lane writes
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) woff[i * 4 + j] = lds_byte(s, g, 0, i * 4 + j);
+    // The filt tiles of this producer's next chunk are prefetched by LDS-DMA into the wave's own 6 KiB landing zone
+    // right after stage 1 has read the zone, three ticks before they are needed; no prefetch lives in registers
+    // (mfma_tile.hpp, lds_dma16).  The zone is the image of the chunk's 16 rows x 384 contiguous bytes (this
+    // tile-wave's 4 tiles in 16 time rows): piece j = 64 i + lane of instruction i is bytes 16 (j % 24) of row
+    // j / 24, so one instruction reads 2 2/3 whole rows (measured: 64 scattered 16-byte pieces per instruction
+    // cost 185-280 cycles of issue each, whole rows about a quarter of that).
+    char* const zone = zones + p * ZONE_BYTES;
+    const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
+    int frow[6], fcol[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const int j = 64 * i + lane; frow[i] = j / 24; fcol[i] = (j % 24) * 16; }
+    const char* const wave_tiles = (const char*)(tiles + (size_t)tw * 4 * TILE_DOUBLES);
+    auto fetch = [&](int ch) {
+        const int n_hi = a.N - 1 - ch * CHUNK;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int n = n_hi - frow[i];                        // rows past the start (n < 1) are clamped, never handed over
+            lds_dma16(wave_tiles + (size_t)(n < 1 ? 1 : n) * tstride * 8 + fcol[i], zone_lds + 1024 * i);
+        }
+    };
+    lds_dma_wait_all();                                        // retire the loads of Q, R before the first DMA
+    if (p < n_chunks) fetch(p);
+    // Chunk ch passes through three stages in the ticks ch-3, ch-2, ch-1 (one workgroup barrier per tick), so in
+    // every tick the three producers each run a different stage of three different chunks: equal work per SIMD
+    // and tick.  All state between stages stays in this wave's registers.
+    double mf[P], Sf[P][P], mp[P], Sp[P][P], A[P][P], X[P][P], rpiv[P];
+    for (int t = -3; t < n_chunks; ++t) {
+        const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
+        if (ch1 % 3 == p) {
+            // ---- stage 1 of chunk ch1: take the fetched tiles, start the next fetch, predict ----
+            if (ch1 < n_chunks) {
+                lds_dma_wait_all();
+                double buf[TILE_DOUBLES];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const double2 v = *(const double2*)(zone + 96 * lane + 16 * k);      // lane = 4 s + g
+                    buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
+                }
+                lds_reads_done();
+                if (ch1 + 3 < n_chunks) fetch(ch1 + 3);
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+#pragma unroll
+                    for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
+                    mf[i] = buf[i * 4 + 3];
+                }
+                predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
+            }
+        } else if (ch2 >= 0 && ch2 % 3 == p) {
+            // ---- stage 2 of chunk ch2: T^T = (Sigma_f Q^T)^T (standard.py:175), LU of Sigma-, forward sweep ----
+            if (ch2 < n_chunks) {
+                double T[P][P];
+                mm_nt<P, P, P>(Sf, Q, T);
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
+                lu_factor_fwd<P, P>(A, X, rpiv);
+            }
+        } else if (ch3 >= 0) {
+            // ---- stage 3 of chunk ch3: back substitution, X = solve(Sigma-, T^T) = G^T (standard.py:176), hand-off ----
+            if (ch3 < n_chunks) {
+                lu_back<P, P>(A, X, rpiv);
+                const int n = a.N - 1 - ch3 * CHUNK - s;
+                if (n >= 1) {
+                    char* o = lds_raw + (ch3 & 1) * BUF_BYTES;
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+#pragma unroll
+                        for (int j = 0; j < P; ++j) {
+                            *(double*)(o + woff[i * 4 + j]) = Sp[i][j];             // M-   (which = 0)
+                            *(double*)(o + woff[i * 4 + j] + 128) = X[i][j];        // G~^T (which = 1)
+                            *(double*)(o + woff[i * 4 + j] + 256) = Sf[i][j];       // M_f  (which = 2)
+                        }
+                        *(double*)(o + woff[i * 4 + 3]) = mp[i];
+                        *(double*)(o + woff[i * 4 + 3] + 256) = mf[i];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* __restrict__ tiles, int D) {
     __shared__ __attribute__((aligned(16))) char lds_all[2 * BUF_BYTES];
     __shared__ __attribute__((aligned(16))) char zones[3 * ZONE_BYTES];      // the producers' prefetch landing zones
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;    // 0 = consumer; producers q = wave - 1 own ch = q (mod 3)
@@ -75,101 +177,7 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
     double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)tw * 64;
 
     if (wave >= 1) {
-        // ---------------- producers: one lane per (step-in-chunk, tile) ----------------
-        const int p = wave - 1;
-        const int s = lane >> 2, g = lane & 3;
-        int tau = tw * 4 + g;
-        if (tau >= n_tiles) tau = n_tiles - 1;
-        const int b = tau / D, blk = tau - b * D;
-        double Q[P][P], R[P][P];
-        load_block_consts<P>(a, blk, b, Q, R);
-        int woff[12];                                              // LDS byte offsets of the 12 slots this lane writes
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) woff[i * 4 + j] = lds_byte(s, g, 0, i * 4 + j);
-        // The filt tiles of this producer's next chunk are prefetched by LDS-DMA into the wave's own 6 KiB landing zone
-        // right after stage 1 has read the zone, three ticks before they are needed; no prefetch lives in registers
-        // (mfma_tile.hpp, lds_dma16).  The zone is the image of the chunk's 16 rows x 384 contiguous bytes (this
-        // tile-wave's 4 tiles in 16 time rows): piece j = 64 i + lane of instruction i is bytes 16 (j % 24) of row
-        // j / 24, so one instruction reads 2 2/3 whole rows (measured: 64 scattered 16-byte pieces per instruction
-        // cost 185-280 cycles of issue each, whole rows about a quarter of that).
-        char* const zone = zones + p * ZONE_BYTES;
-        const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
-        int frow[6], fcol[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { const int j = 64 * i + lane; frow[i] = j / 24; fcol[i] = (j % 24) * 16; }
-        const char* const wave_tiles = (const char*)(tiles + (size_t)tw * 4 * TILE_DOUBLES);
-        auto fetch = [&](int ch) {
-            const int n_hi = a.N - 1 - ch * CHUNK;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int n = n_hi - frow[i];                        // rows past the start (n < 1) are clamped, never handed over
-                lds_dma16(wave_tiles + (size_t)(n < 1 ? 1 : n) * tstride * 8 + fcol[i], zone_lds + 1024 * i);
-            }
-        };
-        lds_dma_wait_all();                                        // retire the loads of Q, R before the first DMA
-        if (p < n_chunks) fetch(p);
-        // Chunk ch passes through three stages in the ticks ch-3, ch-2, ch-1 (one workgroup barrier per tick), so in
-        // every tick the three producers each run a different stage of three different chunks: equal work per SIMD
-        // and tick.  All state between stages stays in this wave's registers.
-        double mf[P], Sf[P][P], mp[P], Sp[P][P], A[P][P], X[P][P], rpiv[P];
-        for (int t = -3; t < n_chunks; ++t) {
-            const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
-            if (ch1 % 3 == p) {
-                // ---- stage 1 of chunk ch1: take the fetched tiles, start the next fetch, predict ----
-                if (ch1 < n_chunks) {
-                    lds_dma_wait_all();
-                    double buf[TILE_DOUBLES];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const double2 v = *(const double2*)(zone + 96 * lane + 16 * k);      // lane = 4 s + g
-                        buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
-                    }
-                    lds_reads_done();
-                    if (ch1 + 3 < n_chunks) fetch(ch1 + 3);
-#pragma unroll
-                    for (int i = 0; i < P; ++i) {
-#pragma unroll
-                        for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
-                        mf[i] = buf[i * 4 + 3];
-                    }
-                    predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
-                }
-            } else if (ch2 >= 0 && ch2 % 3 == p) {
-                // ---- stage 2 of chunk ch2: T^T = (Sigma_f Q^T)^T (standard.py:175), LU of Sigma-, forward sweep ----
-                if (ch2 < n_chunks) {
-                    double T[P][P];
-                    mm_nt<P, P, P>(Sf, Q, T);
-#pragma unroll
-                    for (int i = 0; i < P; ++i)
-#pragma unroll
-                        for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
-                    lu_factor_fwd<P, P>(A, X, rpiv);
-                }
-            } else if (ch3 >= 0) {
-                // ---- stage 3 of chunk ch3: back substitution, X = solve(Sigma-, T^T) = G^T (standard.py:176), hand-off ----
-                if (ch3 < n_chunks) {
-                    lu_back<P, P>(A, X, rpiv);
-                    const int n = a.N - 1 - ch3 * CHUNK - s;
-                    if (n >= 1) {
-                        char* o = lds_raw + (ch3 & 1) * BUF_BYTES;
-#pragma unroll
-                        for (int i = 0; i < P; ++i) {
-#pragma unroll
-                            for (int j = 0; j < P; ++j) {
-                                *(double*)(o + woff[i * 4 + j]) = Sp[i][j];             // M-   (which = 0)
-                                *(double*)(o + woff[i * 4 + j] + 128) = X[i][j];        // G~^T (which = 1)
-                                *(double*)(o + woff[i * 4 + j] + 256) = Sf[i][j];       // M_f  (which = 2)
-                            }
-                            *(double*)(o + woff[i * 4 + 3]) = mp[i];
-                            *(double*)(o + woff[i * 4 + 3] + 256) = mf[i];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
+        tile3_gain_producers(a, tiles, D, tw, wave, lane, n_tiles, tstride, n_chunks, lds_raw, zones);
     } else {
         // ---------------- consumer: the carry recursion on MFMA tiles ----------------
         const TileCoord tc = tile_coord<1>(tw, lane, n_tiles);              // (b, blk) not needed here
@@ -264,7 +272,6 @@ struct FenrirObs {
 };
 
 __global__ void __launch_bounds__(256) fenrir_bwd_tile3_kernel(SolveArgs a, const double* __restrict__ tiles, int D, FenrirObs ob) {
-    constexpr int P = 3;
     __shared__ __attribute__((aligned(16))) char lds_all[2 * BUF_BYTES];
     __shared__ __attribute__((aligned(16))) char zones[3 * ZONE_BYTES];      // the producers' prefetch landing zones
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;    // 0 = consumer; producers q = wave - 1 own ch = q (mod 3)
@@ -284,101 +291,7 @@ __global__ void __launch_bounds__(256) fenrir_bwd_tile3_kernel(SolveArgs a, cons
     char* const lds_raw = lds_all;
 
     if (wave >= 1) {
-        // ---------------- producers: one lane per (step-in-chunk, tile) ----------------
-        const int p = wave - 1;
-        const int s = lane >> 2, g = lane & 3;
-        int tau = tw * 4 + g;
-        if (tau >= n_tiles) tau = n_tiles - 1;
-        const int b = tau / D, blk = tau - b * D;
-        double Q[P][P], R[P][P];
-        load_block_consts<P>(a, blk, b, Q, R);
-        int woff[12];                                              // LDS byte offsets of the 12 slots this lane writes
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) woff[i * 4 + j] = lds_byte(s, g, 0, i * 4 + j);
-        // The filt tiles of this producer's next chunk are prefetched by LDS-DMA into the wave's own 6 KiB landing zone
-        // right after stage 1 has read the zone, three ticks before they are needed; no prefetch lives in registers
-        // (mfma_tile.hpp, lds_dma16).  The zone is the image of the chunk's 16 rows x 384 contiguous bytes (this
-        // tile-wave's 4 tiles in 16 time rows): piece j = 64 i + lane of instruction i is bytes 16 (j % 24) of row
-        // j / 24, so one instruction reads 2 2/3 whole rows (measured: 64 scattered 16-byte pieces per instruction
-        // cost 185-280 cycles of issue each, whole rows about a quarter of that).
-        char* const zone = zones + p * ZONE_BYTES;
-        const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
-        int frow[6], fcol[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { const int j = 64 * i + lane; frow[i] = j / 24; fcol[i] = (j % 24) * 16; }
-        const char* const wave_tiles = (const char*)(tiles + (size_t)tw * 4 * TILE_DOUBLES);
-        auto fetch = [&](int ch) {
-            const int n_hi = a.N - 1 - ch * CHUNK;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int n = n_hi - frow[i];                        // rows past the start (n < 1) are clamped, never handed over
-                lds_dma16(wave_tiles + (size_t)(n < 1 ? 1 : n) * tstride * 8 + fcol[i], zone_lds + 1024 * i);
-            }
-        };
-        lds_dma_wait_all();                                        // retire the loads of Q, R before the first DMA
-        if (p < n_chunks) fetch(p);
-        // Chunk ch passes through three stages in the ticks ch-3, ch-2, ch-1 (one workgroup barrier per tick), so in
-        // every tick the three producers each run a different stage of three different chunks: equal work per SIMD
-        // and tick.  All state between stages stays in this wave's registers.
-        double mf[P], Sf[P][P], mp[P], Sp[P][P], A[P][P], X[P][P], rpiv[P];
-        for (int t = -3; t < n_chunks; ++t) {
-            const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
-            if (ch1 % 3 == p) {
-                // ---- stage 1 of chunk ch1: take the fetched tiles, start the next fetch, predict ----
-                if (ch1 < n_chunks) {
-                    lds_dma_wait_all();
-                    double buf[TILE_DOUBLES];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const double2 v = *(const double2*)(zone + 96 * lane + 16 * k);      // lane = 4 s + g
-                        buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
-                    }
-                    lds_reads_done();
-                    if (ch1 + 3 < n_chunks) fetch(ch1 + 3);
-#pragma unroll
-                    for (int i = 0; i < P; ++i) {
-#pragma unroll
-                        for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
-                        mf[i] = buf[i * 4 + 3];
-                    }
-                    predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
-                }
-            } else if (ch2 >= 0 && ch2 % 3 == p) {
-                // ---- stage 2 of chunk ch2: T^T = (Sigma_f Q^T)^T (standard.py:175), LU of Sigma-, forward sweep ----
-                if (ch2 < n_chunks) {
-                    double T[P][P];
-                    mm_nt<P, P, P>(Sf, Q, T);
-#pragma unroll
-                    for (int i = 0; i < P; ++i)
-#pragma unroll
-                        for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
-                    lu_factor_fwd<P, P>(A, X, rpiv);
-                }
-            } else if (ch3 >= 0) {
-                // ---- stage 3 of chunk ch3: back substitution, X = solve(Sigma-, T^T) = G^T (standard.py:176), hand-off ----
-                if (ch3 < n_chunks) {
-                    lu_back<P, P>(A, X, rpiv);
-                    const int n = a.N - 1 - ch3 * CHUNK - s;
-                    if (n >= 1) {
-                        char* o = lds_raw + (ch3 & 1) * BUF_BYTES;
-#pragma unroll
-                        for (int i = 0; i < P; ++i) {
-#pragma unroll
-                            for (int j = 0; j < P; ++j) {
-                                *(double*)(o + woff[i * 4 + j]) = Sp[i][j];             // M-   (which = 0)
-                                *(double*)(o + woff[i * 4 + j] + 128) = X[i][j];        // G~^T (which = 1)
-                                *(double*)(o + woff[i * 4 + j] + 256) = Sf[i][j];       // M_f  (which = 2)
-                            }
-                            *(double*)(o + woff[i * 4 + 3]) = mp[i];
-                            *(double*)(o + woff[i * 4 + 3] + 256) = mf[i];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
+        tile3_gain_producers(a, tiles, D, tw, wave, lane, n_tiles, tstride, n_chunks, lds_raw, zones);
     } else {
         // ---------------- consumer: the backward filter on MFMA tiles ----------------
         __builtin_amdgcn_s_setprio(3);
