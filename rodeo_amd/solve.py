@@ -288,9 +288,39 @@ def _solve_filter(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, int
     return {"state_pred": plan.pred_host(), "state_filt": plan.state_host()}
 
 
+def _pad_two_to_three(ode_weight, ode_init, prior_pars):
+    """
+    n_bstate = 2 has no MFMA-tile kernels of its own; it runs on the n_bstate = 3 ones with a third state component that
+    is decoupled from the other two: Q = diag(Q, 1), R = diag(R, 1), zero weight, zero initial value.  Its cross
+    covariances start as exact zeros and stay exact zeros (products with and sums of zeros), the pivoted LU never picks
+    its row for the other two columns, and the draws of the first two components use the same normals -- so the leading
+    2 x 2 part is the n_bstate = 2 computation, term for term.
+    """
+    W, x0 = np.asarray(ode_weight, dtype=np.float64), np.asarray(ode_init, dtype=np.float64)
+    Q, R = (np.asarray(a, dtype=np.float64) for a in prior_pars)
+
+    def grow(M):                                        # (..., 2, 2) -> (..., 3, 3) with a one in the corner
+        out = np.zeros(M.shape[:-2] + (3, 3))
+        out[..., :2, :2] = M
+        out[..., 2, 2] = 1.0
+        return out
+    W3 = np.concatenate([W, np.zeros(W.shape[:-1] + (1,))], axis=-1)
+    x3 = np.concatenate([x0, np.zeros(x0.shape[:-1] + (1,))], axis=-1)
+    return W3, x3, (grow(Q), grow(R))
+
+
+def _two_state_on_tiles(ode_weight, kalman_type):
+    W = np.shape(ode_weight)
+    return kalman_type == "standard" and len(W) >= 3 and W[-1] == 2 and W[-2] == 1
+
+
 def solve_mv(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars,
              kalman_type="standard", **params):
     """Mean and variance of the stochastic ODE solver (src/rodeo/solve.py:208-302)."""
+    if _two_state_on_tiles(ode_weight, kalman_type):
+        W3, x3, pp3 = _pad_two_to_three(ode_weight, ode_init, prior_pars)
+        m, v = solve_mv(key, ode_fun, W3, x3, t_min, t_max, n_steps, interrogate, pp3, kalman_type, **params)
+        return np.ascontiguousarray(m[..., :2]), np.ascontiguousarray(v[..., :2, :2])
     plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
                      **params)
     plan.mv(key)
@@ -300,6 +330,10 @@ def solve_mv(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrog
 def solve_sim(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars,
               kalman_type="standard", **params):
     """Draw one sample solution per trajectory (src/rodeo/solve.py:125-205)."""
+    if _two_state_on_tiles(ode_weight, kalman_type):
+        W3, x3, pp3 = _pad_two_to_three(ode_weight, ode_init, prior_pars)
+        return np.ascontiguousarray(solve_sim(key, ode_fun, W3, x3, t_min, t_max, n_steps, interrogate, pp3, kalman_type,
+                                              **params)[..., :2])
     plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
                      **params)
     plan.sim(key)

@@ -535,3 +535,25 @@ def test_integration_md_stub_runs(ra):
     m2, v2 = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, 2.0, 40, ra.interrogate.interrogate_kramer,
                          s["prior"], theta=s["theta"])
     assert m.shape == m2.shape and np.max(np.abs(m - m2)) < 1e-9 and np.max(np.abs(v - v2)) < 1e-9 * np.max(np.abs(v2))
+
+
+@pytest.mark.parametrize("name", ["kramer", "rodeo", "schober"])
+def test_two_state_blocks_run_on_the_three_state_tiles(ra, name):
+    """n_deriv = 2 through solve_mv / solve_sim: padded with a decoupled third component and run on the MFMA tiles --
+    against the oracle at n_deriv = 2 and against the lane-per-trajectory n_bstate = 2 kernels (SolvePlan)."""
+    g, o = _itg(ra, name)
+    B = 6
+    s = fitz_problem(ra, N=120, t_max=3.0, sigma=.5, p=2, B=B)
+    args = (s["W"], s["x0"], 0.0, 3.0, 120)
+    m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    assert m.shape == (B, 121, 2, 2) and v.shape == (B, 121, 2, 2, 2)
+    assert np.max(np.abs(m - mo)) < 1e-9 * max(1.0, np.max(np.abs(mo)))
+    _vclose(v, vo, 1e-8)
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    plan.mv(None)
+    ml, vl = plan.state_host()
+    assert np.max(np.abs(m - ml)) < 1e-10 * max(1.0, np.max(np.abs(ml)))
+    x = ra.solve_sim(5, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    xo = scan.solve_sim(5, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    assert x.shape == (B, 121, 2, 2) and np.max(np.abs(x - xo)) < 1e-7
