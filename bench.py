@@ -4,18 +4,19 @@ bench.py -- headline benchmark of BASELINE.json: trajectory-steps per second (OD
 probabilistic ODE solve, FitzHugh-Nagumo n_vars=2 q(n_deriv)=3, 4000 steps, `solve_mv` + `interrogate_kramer`,
 1024 trajectories per GPU (BASELINE.json configs[1]; SURVEY.md section 8d "C2").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: spawns its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W                  (the driver's launch: RANK / WORLD_SIZE from the env)
 
 One "step" = one complete solve (forward filter kernel + backward smoother kernel) of this rank's batch with all
 inputs and outputs resident in HBM.  The path shards by independent trajectories: rank r owns global trajectories
 [r*B, (r+1)*B) ("weak" scaling, no data-path collective).  Timing: barrier + device sync on both sides of exactly K
 steps, MAX over ranks; rank 0 prints ONE JSON line.
 
-torch is used only as CPU-side rendezvous plumbing (gloo) when N > 1; it never touches the GPU.  The device work goes
-through librodeo_kalman.so (ctypes); barrier / max-reduce between ranks run over RCCL inside that library when the
-communicator comes up, else over gloo.
+No torch in these processes: the ranks meet over rodeo_amd.hostgroup (standard-library TCP star; carries the 128-byte
+ncclUniqueId and the max-over-ranks), the device work goes through librodeo_kalman.so (ctypes), and the barriers
+around the timed region run over RCCL inside that library when the communicator comes up on every rank (else over the
+host channel; `--require-rccl` turns that fallback into a non-zero exit).
 """
 import argparse
 import json
@@ -48,8 +49,29 @@ def make_problem(ra, rank):
     return W, x0, theta, prior
 
 
-def cpu_baseline(W, x0, theta, prior):
-    """Plain-C restatement of the reference algorithm (oracle/c, 'port') on the host cores, bounded sample."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(W, x0, theta, prior, budget_s=14.0):
+    """
+    The reference algorithm on the host cores (SURVEY.md section 8d "CPU baseline"; the protocol of the reference's own
+    examples/timings.py:28-46 -- warm-up, then the mean over repeated runs), as a bounded sample of the SAME workload:
+      port   -- plain-C restatement (oracle/c, -O3 -march=native, compile-time block sizes, OpenMP over trajectories).
+                Outputs and per-thread scratch are allocated and paged in ONCE, outside the timing; only the C passes are
+                timed (omp_get_wtime inside the library).  Thread sweep {1, 8, 32, 64, 128, all}: `value` is the best.
+      numpy  -- the batch-vectorised NumPy restatement (oracle/scan.py: einsum / batched solves over the 1024
+                trajectories, what vmap + XLA do), a few hundred steps of the same problem.
+    Both stand in for rodeo's JAX-CPU path, which cannot run here (no jax).
+    """
+    out = {"value": None, "unit": "trajectory-steps/s", "cores": 0, "kind": "port", "sample": ""}
     try:
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "c"), "native"], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -57,23 +79,47 @@ def cpu_baseline(W, x0, theta, prior):
         native = os.path.join(ROOT, "oracle", "c", "librk_oracle_native.so")
         if os.path.exists(native):
             c_port._PATH = native
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        # calibrate on one pass over the batch, then repeat the pass until ~12 s of CPU work have been timed
-        n = N_TRAJ
-        t0 = time.perf_counter()
-        c_port.solve_mv("fitzhugh_nagumo", "kramer", W, x0[:n], 0.0, T_MAX, N_STEPS, prior, theta[:n], cores)
-        dt1 = max(time.perf_counter() - t0, 1e-3)
-        reps = int(min(max(12.0 / dt1, 1), 200))
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            c_port.solve_mv("fitzhugh_nagumo", "kramer", W, x0[:n], 0.0, T_MAX, N_STEPS, prior, theta[:n], cores)
-        dt = time.perf_counter() - t0
-        return {"value": reps * n * N_STEPS / dt, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} passes over the {n} trajectories x {N_STEPS} steps ({dt:.1f} s), solve_mv+kramer, "
-                          f"plain C -O3 -march=native restatement of the reference algorithm (oracle/c), OpenMP over "
-                          f"trajectories on {cores} host threads"}
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        counts = sorted({t for t in (1, 8, 32, 64, 128, avail) if t <= avail})
+        ts = c_port.TimedSolve("fitzhugh_nagumo", "kramer", W, x0, 0.0, T_MAX, N_STEPS, prior, theta, max_threads=avail)
+        per_leg = budget_s / (len(counts) + 1)
+        sweep, spent = {}, 0.0
+        for nt in counts:
+            n_traj = N_TRAJ if nt > 1 else 128                   # one thread: a 128-trajectory sample of the batch
+            warm = ts.run(1, nt, n_traj)                         # warm-up pass (also calibrates)
+            reps = int(min(max(per_leg / max(warm, 1e-4), 1), 400))
+            sec = ts.run(reps, nt, n_traj)
+            spent += warm + sec
+            sweep[str(nt)] = reps * n_traj * N_STEPS / sec
+        best_nt = max(sweep, key=sweep.get)
+        one = sweep.get("1")
+        out.update({
+            "value": sweep[best_nt], "cores": int(best_nt), "value_best": sweep[best_nt], "threads_best": int(best_nt),
+            "value_1thread": one, "threads_available": avail, "cpu_model": _cpu_model(),
+            "scaling_efficiency_at_best": (sweep[best_nt] / (int(best_nt) * one)) if one else None,
+            "thread_sweep": sweep,
+            "sample": f"solve_mv + kramer on the C2 problem ({N_STEPS} steps): repeated passes over the {N_TRAJ} "
+                      f"trajectories (128 of them on one thread), ~{per_leg:.1f} s per thread count, {spent:.1f} s in "
+                      f"all; plain C -O3 -march=native restatement of the reference algorithm (oracle/c), outputs and "
+                      f"scratch preallocated and paged in outside the timing"})
     except Exception as e:                                   # the baseline is a report, never a reason to fail
-        return {"value": None, "unit": "trajectory-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        out["sample"] = f"failed: {e}"
+        return out
+    try:                                                     # NumPy leg: the same problem, first `n_np` steps
+        from oracle import scan, odes, interrogations as oi
+        n_np = 300
+        t_end = T_MAX * n_np / N_STEPS
+        scan.solve_mv(None, odes.fitzhugh_nagumo, W, x0, 0.0, t_end / 10, n_np // 10, oi.interrogate_kramer, prior,
+                      theta=theta)                           # warm-up
+        t0 = time.perf_counter()
+        scan.solve_mv(None, odes.fitzhugh_nagumo, W, x0, 0.0, t_end, n_np, oi.interrogate_kramer, prior, theta=theta)
+        dt = time.perf_counter() - t0
+        out["numpy_batched"] = {"value": N_TRAJ * n_np / dt, "unit": "trajectory-steps/s",
+                                "sample": f"oracle/scan.py solve_mv, {N_TRAJ} trajectories x the first {n_np} steps "
+                                          f"(dt as in C2), batch-vectorised NumPy, {dt:.1f} s"}
+    except Exception as e:                                   # noqa: BLE001
+        out["numpy_batched"] = {"value": None, "sample": f"failed: {e}"}
+    return out
 
 
 def main():
@@ -82,17 +128,21 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--require-rccl", action="store_true", help="N > 1: exit non-zero if RCCL does not come up on every rank")
+    ap.add_argument("--comm", choices=["rccl", "host"], default="rccl", help="N > 1: what carries the barriers")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # own launcher: N rank processes of this script, started before anything here has touched a GPU
+        from rodeo_amd import hostgroup
+        sys.exit(hostgroup.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                       timeout=float(os.environ.get("RK_BENCH_TIMEOUT", "1500"))))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
-    import rodeo_amd as ra                      # loads librodeo_kalman.so BEFORE torch's bundled ROCm libraries
-    from rodeo_amd import _lib
+    import rodeo_amd as ra
+    from rodeo_amd import _lib, hostgroup, shard
     import ctypes as C
     lib = _lib.load()
     n_dev = C.c_int(0)
@@ -101,67 +151,36 @@ def main():
         print(f"[rank {rank}] only {n_dev.value} GPU(s) visible; sharing device {local_rank % n_dev.value}", file=sys.stderr)
     dev = ra.Device(local_rank % max(n_dev.value, 1))
 
-    dist = None
-    comm = "none"
-    hard_exit = False
+    group = hostgroup.HostGroup.from_env(timeout=float(os.environ.get("RK_BENCH_RDZV_TIMEOUT", "180")))
+    rccl, comm, hard_exit = None, "none", False
     if world > 1:
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)                     # gloo and RCCL print diagnostics on stdout; keep stdout for the one JSON line
-        try:
-            import torch.distributed as dist
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            comm = "gloo"
-            # RCCL communicator inside the library (only used for the barriers around the timed region: the data path has
-            # no collective).  Set up in a helper thread with a deadline, and used only if EVERY rank got it -- a rank
-            # stuck in the bootstrap must not take the scaling run down; gloo then carries the barriers.
-            import threading
-            import torch
-            state = {"ok": False, "err": None}
-
-            uid = (C.c_char * _lib.COMM_UID_BYTES)()
-            if rank == 0:
-                try:
-                    _lib.check(lib.rk_comm_uid(uid))
-                except Exception as e:                       # noqa: BLE001
-                    state["err"] = e
-            box = [bytes(uid), state["err"] is None]
-            dist.broadcast_object_list(box, src=0)           # (gloo, main thread)
-            uid2 = (C.c_char * _lib.COMM_UID_BYTES).from_buffer_copy(box[0])
-
-            def _init():
-                try:
-                    _lib.check(lib.rk_comm_init(dev.h, rank, world, uid2))
-                    state["ok"] = True
-                except Exception as e:                       # noqa: BLE001
-                    state["err"] = e
-            stuck = False
-            if box[1]:
-                th = threading.Thread(target=_init, daemon=True)
-                th.start()
-                th.join(timeout=float(os.environ.get("RK_BENCH_RCCL_TIMEOUT", "90")))
-                stuck = th.is_alive()
-            flag = torch.tensor([1 if (state["ok"] and not stuck) else 0], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes part, stuck helper thread or not
-            if int(flag.item()) == 1:
+        comm = "host-tcp"
+        if args.comm == "rccl":
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)                 # RCCL prints diagnostics on stdout; keep stdout for the one JSON line
+            try:
+                rccl, hard_exit, why = shard.init_rccl_or_fail(
+                    dev, group, deadline=float(os.environ.get("RK_BENCH_RCCL_TIMEOUT", "90")))
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
+            if rccl is not None:
                 comm = "rccl"
             else:
-                why = "timed out" if stuck else (state["err"] or "another rank failed")
-                print(f"[rank {rank}] RCCL communicator unavailable ({why}); using gloo for barriers", file=sys.stderr)
-                if state["ok"] and not stuck:
-                    lib.rk_comm_destroy(dev.h)
-                hard_exit = stuck
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+                print(f"[rank {rank}] RCCL communicator unavailable ({why}); host channel carries the barriers",
+                      file=sys.stderr)
+                if args.require_rccl:
+                    sys.stdout.flush(); sys.stderr.flush()
+                    os._exit(3)            # every rank takes this branch (the outcome was agreed over the host channel)
 
     def barrier():
         dev.sync()
-        if comm == "rccl":
-            _lib.check(lib.rk_comm_barrier(dev.h))
-        elif dist is not None:
-            dist.barrier()
+        if rccl is not None:
+            rccl.barrier()
+        else:
+            group.barrier()
 
     W, x0, theta, prior = make_problem(ra, rank)
     plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, x0, 0.0, T_MAX, N_STEPS, ra.interrogate.interrogate_kramer, prior,
@@ -177,11 +196,7 @@ def main():
     dev_ms = dev.timer_stop()                  # HIP events on the library's stream (also synchronises)
     barrier()
     wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall = float(group.allreduce(wall, "max"))
 
     # ---- per-kernel device time (HIP events around each launch), outside the timed region ----
     dev.profile_enable(True)
@@ -207,13 +222,15 @@ def main():
         achieved = a_dom * units / (kern_ms[dom] * 1e-3) / 1e9
         solve_ms = sum(kern_ms.values())
         # HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE corrected x2, WRITE_SIZE), if recorded
-        traffic = None
+        # (not measured by this run: counters need their own rocprofv3 pass -- scripts/collect_profiles.sh; the file is named)
+        traffic, traffic_src = None, None
         try:
             pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
             if pm:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["kernels"][dom]["hbm_bytes_corrected"]
+                traffic_src = "profiles/" + pm[-1] + " (separate rocprofv3 --pmc passes of this command, committed)"
         except Exception:
-            traffic = None
+            traffic, traffic_src = None, None
         out = {
             "metric": "ODE steps/sec x batch (trajectory-steps/s), FitzHugh-Nagumo q=3, 4000 steps, solve_mv",
             "value": world * units * args.steps / wall,
@@ -231,7 +248,7 @@ def main():
             "device_ms_per_step": dev_ms / args.steps,
             "kernels_ms": kern_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_traj_step": a_dom},
             "roofline_solve": {"bound": "hbm", "achieved": (a_fwd + a_bwd) * units / (solve_ms * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -252,12 +269,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(W, x0, theta, prior)
         print(json.dumps(out), flush=True)
 
-    if comm == "rccl":
-        lib.rk_comm_destroy(dev.h)
-    if dist is not None and not hard_exit:
-        dist.barrier()
-        dist.destroy_process_group()
-    if hard_exit:                                    # a helper thread is still inside the RCCL bootstrap
+    if rccl is not None:
+        rccl.close()
+    group.barrier()
+    group.close()
+    if hard_exit:                                    # a helper thread is still inside the RCCL bootstrap (agreed by all ranks)
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(0)
 

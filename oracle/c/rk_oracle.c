@@ -11,6 +11,12 @@
  * and, like the reference, STORES the predicted moments of every step (solve.py:93-96) and reads them back in the
  * backward pass -- it is the reference's algorithm, not the GPU kernel's.
  *
+ * Timing hygiene (bench.py's cpu_baseline leg): `rko_solve_mv_ws` works on buffers the caller allocated ONCE
+ * (outputs + one scratch area per thread for the stored predictions), which `rko_first_touch` has paged in with the
+ * same static thread schedule, so that neither malloc nor first-touch page faults fall into the timed region; the
+ * per-trajectory routine is force-inlined into callers with compile-time (n_block, n_bstate) for the benchmark
+ * shapes so that gcc unrolls the p x p loops.
+ *
  * Layout: the reference's, batch first: mean (B, N+1, d, p), var (B, N+1, d, p, p); theta (B, 3); x0 (B, d, p);
  * W (d, 1, p), Q (d, p, p), R (d, p, p) shared by all trajectories.  OpenMP over trajectories.
  */
@@ -28,7 +34,7 @@ enum { RHS_FITZ = 1, RHS_LORENZ = 2, RHS_HIGHER = 3 };
 enum { ITG_RODEO = 0, ITG_SCHOBER = 1, ITG_KRAMER = 2 };
 
 /* f_b(X, t) and the block-diagonal Jacobian row J[b][:] = d f_b / d X[b][:] */
-static void rhs_eval(int rhs, int d, int p, const double* X /* d x p */, double t, const double* th, double* f,
+static inline __attribute__((always_inline)) void rhs_eval(int rhs, int d, int p, const double* X /* d x p */, double t, const double* th, double* f,
                      double* J /* d x p or NULL */) {
     if (J) memset(J, 0, sizeof(double) * d * p);
     if (rhs == RHS_FITZ) {
@@ -49,7 +55,7 @@ static void rhs_eval(int rhs, int d, int p, const double* X /* d x p */, double 
 }
 
 /* X = A^{-1} B, LU with partial pivoting; A (n x n), B (n x nr) row-major, destroyed */
-static void lu_solve(int n, int nr, double* A, double* B) {
+static inline __attribute__((always_inline)) void lu_solve(const int n, int nr, double* A, double* B) {
     for (int k = 0; k < n; ++k) {
         int piv = k;
         double best = fabs(A[k * n + k]);
@@ -74,7 +80,7 @@ static void lu_solve(int n, int nr, double* A, double* B) {
         }
 }
 
-static void solve_one(int rhs, int itg, int N, int d, int p, double t_min, double t_max, const double* W,
+static inline __attribute__((always_inline)) void solve_one(const int rhs, const int itg, const int N, const int d, const int p, double t_min, double t_max, const double* W,
                       const double* x0, const double* Q, const double* R, const double* th, double* mean,
                       double* var, double* mpred, double* vpred) {
     const int pp = p * p;
@@ -204,34 +210,101 @@ static void solve_one(int rhs, int itg, int N, int d, int p, double t_min, doubl
     }
 }
 
-/* returns 0 on success; nthreads <= 0 -> OpenMP default */
-int rko_solve_mv(int rhs, int itg, int B, int N, int d, int p, double t_min, double t_max, const double* W,
-                 const double* x0, const double* Q, const double* R, const double* theta, int n_theta, double* mean,
-                 double* var, int nthreads) {
+/* compile-time (n_block, n_bstate) instances for the benchmark shapes; anything else runs the runtime-size loops */
+static void solve_one_dispatch(int rhs, int itg, int N, int d, int p, double t_min, double t_max, const double* W,
+                               const double* x0b, const double* Q, const double* R, const double* thb, double* mean_b,
+                               double* var_b, double* mpred, double* vpred) {
+    if (d == 2 && p == 3) solve_one(rhs, itg, N, 2, 3, t_min, t_max, W, x0b, Q, R, thb, mean_b, var_b, mpred, vpred);
+    else if (d == 3 && p == 4) solve_one(rhs, itg, N, 3, 4, t_min, t_max, W, x0b, Q, R, thb, mean_b, var_b, mpred, vpred);
+    else if (d == 2 && p == 4) solve_one(rhs, itg, N, 2, 4, t_min, t_max, W, x0b, Q, R, thb, mean_b, var_b, mpred, vpred);
+    else if (d == 2 && p == 5) solve_one(rhs, itg, N, 2, 5, t_min, t_max, W, x0b, Q, R, thb, mean_b, var_b, mpred, vpred);
+    else solve_one(rhs, itg, N, d, p, t_min, t_max, W, x0b, Q, R, thb, mean_b, var_b, mpred, vpred);
+}
+
+static int check_shape(int rhs, int itg, int B, int N, int d, int p) {
     if (d > DMAX || p > PMAX || d < 1 || p < 2 || B < 1 || N < 1) return -1;
     if (itg < 0 || itg > ITG_KRAMER || rhs < RHS_FITZ || rhs > RHS_HIGHER) return -2;
-    const size_t ms = (size_t)(N + 1) * d * p, vs = ms * p;
-    int fail = 0;
+    return 0;
+}
+
+/* doubles of per-thread scratch (the stored predictions of one trajectory, solve.py:93-96) */
+size_t rko_scratch_doubles(int N, int d, int p) { return (size_t)(N + 1) * d * p * (1 + (size_t)p); }
+
+/* page in `n_per_traj` doubles per trajectory of `buf` and the threads' scratch with the schedule the solver uses */
+void rko_first_touch(double* buf, size_t n_per_traj, int B, double* scratch, size_t scratch_per_thread, int nthreads) {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
 #pragma omp parallel
     {
-        double* mpred = (double*)malloc(sizeof(double) * ms);
-        double* vpred = (double*)malloc(sizeof(double) * vs);
-        if (!mpred || !vpred) {
-#pragma omp atomic write
-            fail = 1;
-        } else {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num();
+#else
+        const int tid = 0;
+#endif
+        if (scratch) memset(scratch + (size_t)tid * scratch_per_thread, 0, sizeof(double) * scratch_per_thread);
+#pragma omp for schedule(static)
+        for (int b = 0; b < B; ++b)
+            if (buf) memset(buf + (size_t)b * n_per_traj, 0, sizeof(double) * n_per_traj);
+    }
+}
+
+/*
+ * `reps` passes over the B trajectories into caller-owned buffers; scratch holds nthreads x rko_scratch_doubles().
+ * Returns 0 and the wall time of the passes (seconds, measured around the parallel region) in *seconds.
+ */
+int rko_solve_mv_ws(int rhs, int itg, int B, int N, int d, int p, double t_min, double t_max, const double* W,
+                    const double* x0, const double* Q, const double* R, const double* theta, int n_theta, double* mean,
+                    double* var, double* scratch, int reps, int nthreads, double* seconds) {
+    const int rc = check_shape(rhs, itg, B, N, d, p);
+    if (rc) return rc;
+    if (!scratch || reps < 1) return -4;
+    const size_t ms = (size_t)(N + 1) * d * p, vs = ms * p;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    const double t0 = omp_get_wtime();
+#endif
+#pragma omp parallel
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num();
+#else
+        const int tid = 0;
+#endif
+        double* mpred = scratch + (size_t)tid * (ms + vs);
+        double* vpred = mpred + ms;
+        for (int r = 0; r < reps; ++r) {
 #pragma omp for schedule(static)
             for (int b = 0; b < B; ++b)
-                solve_one(rhs, itg, N, d, p, t_min, t_max, W, x0 + (size_t)b * d * p, Q, R,
-                          theta ? theta + (size_t)b * n_theta : NULL, mean + b * ms, var + b * vs, mpred, vpred);
+                solve_one_dispatch(rhs, itg, N, d, p, t_min, t_max, W, x0 + (size_t)b * d * p, Q, R,
+                                   theta ? theta + (size_t)b * n_theta : NULL, mean + b * ms, var + b * vs, mpred, vpred);
         }
-        free(mpred);
-        free(vpred);
     }
-    return fail ? -3 : 0;
+#ifdef _OPENMP
+    if (seconds) *seconds = omp_get_wtime() - t0;
+#else
+    if (seconds) *seconds = 0.0;
+#endif
+    return 0;
+}
+
+/* convenience form for the tests: allocates the scratch itself.  returns 0 on success; nthreads <= 0 -> OpenMP default */
+int rko_solve_mv(int rhs, int itg, int B, int N, int d, int p, double t_min, double t_max, const double* W,
+                 const double* x0, const double* Q, const double* R, const double* theta, int n_theta, double* mean,
+                 double* var, int nthreads) {
+    const int rc = check_shape(rhs, itg, B, N, d, p);
+    if (rc) return rc;
+#ifdef _OPENMP
+    const int nt = nthreads > 0 ? nthreads : omp_get_max_threads();
+#else
+    const int nt = 1;
+#endif
+    double* scratch = (double*)malloc(sizeof(double) * (size_t)nt * rko_scratch_doubles(N, d, p));
+    if (!scratch) return -3;
+    const int rc2 = rko_solve_mv_ws(rhs, itg, B, N, d, p, t_min, t_max, W, x0, Q, R, theta, n_theta, mean, var, scratch,
+                                    1, nt, NULL);
+    free(scratch);
+    return rc2;
 }
 
 int rko_max_threads(void) {

@@ -21,13 +21,14 @@ class LazyMean:
     """The posterior mean of the solve behind a ``basic`` call, downloaded on first use."""
 
     def __init__(self, plan):
-        self._plan, self._gen, self._val = plan, plan.__dict__.get("_generation", 0), None
+        self._plan, self._gen, self._val = plan, plan.generation, None
 
     def _get(self):
         if self._val is None:
-            if self._plan.__dict__.get("_generation", 0) != self._gen:
-                raise RuntimeError("this Xt belongs to an earlier call: its device buffers have been reused; read it "
-                                   "(np.asarray(Xt)) before calling basic() again with the same configuration")
+            if self._plan.generation != self._gen:     # any launch or update() on the (cached, shared) plan since then
+                raise RuntimeError("this Xt belongs to an earlier call: its device buffers have been reused (by basic, "
+                                   "fenrir or any other call with the same configuration); read it (np.asarray(Xt)) "
+                                   "before the next call")
             self._val = np.ascontiguousarray(self._plan.state_host()[0])
         return self._val
 
@@ -59,9 +60,8 @@ def basic(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate
           obs_data, obs_times, obs_loglik, kalman_type="standard", **params):
     plan = cached_plan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
                        **params)        # device buffers are reused across calls with the same configuration
-    plan.__dict__["_generation"] = plan.__dict__.get("_generation", 0) + 1
     plan.mv(key)
-    Xt = LazyMean(plan)
+    Xt = LazyMean(plan)                    # valid until the plan's next launch / update (SolvePlan.generation)
     ind = obs_index(t_min, t_max, n_steps, obs_times)             # basic.py:61-62
     if isinstance(obs_loglik, GaussianObsLoglik):
         ll = gauss_obs_logpost(plan, obs_data, ind, obs_loglik.noise_sd).to_host()

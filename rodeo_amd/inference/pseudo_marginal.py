@@ -30,9 +30,13 @@ class RWAState(NamedTuple):
 
 
 class RWAInfo(NamedTuple):
+    """pseudo_marginal.py:119-132.  ``proposal`` is what the reference's kernel puts there -- the state the chains are in
+    AFTER the accept / reject step (pseudo_marginal.py:377: ``RWAInfo(p_accept, do_accept, new_state)``); the state that
+    was proposed is kept in the additional last field ``proposed``."""
     acceptance_rate: np.ndarray
     is_accepted: np.ndarray
     proposal: RWAState
+    proposed: Optional[RWAState] = None
 
 
 # ---- keys: Philox4x32-10, the same generator the device uses for its draws (rodeo_amd/csrc/philox.hpp) ----
@@ -152,7 +156,8 @@ def build_rmh_transition_energy(proposal_logdensity_fn: Optional[Callable]) -> C
 
 def rmh_proposal(logdensity_fn: Callable, transition_distribution: Callable, compute_acceptance_ratio: Callable,
                  sample_proposal: Callable = static_binomial_sampling) -> Callable:
-    """pseudo_marginal.py:452-483."""
+    """pseudo_marginal.py:452-483: ``generate(rng_key, previous_state) -> (accepted_state, do_accept, p_accept)``.  The
+    proposed state of the last call is kept on the function (``generate.last_proposed``) for ``RWAInfo.proposed``."""
     def generate(rng_key, previous_state: RWAState):
         key_proposal, key_accept, key_logdensity = split(rng_key, 3)
         position = previous_state.position
@@ -163,7 +168,9 @@ def rmh_proposal(logdensity_fn: Callable, transition_distribution: Callable, com
         log_p_accept = compute_acceptance_ratio(previous_state, proposed_state)
         accepted_state, info = sample_proposal(key_accept, log_p_accept, previous_state, proposed_state)
         do_accept, p_accept, _ = info
-        return accepted_state, do_accept, p_accept, proposed_state
+        generate.last_proposed = proposed_state
+        return accepted_state, do_accept, p_accept
+    generate.last_proposed = None
     return generate
 
 
@@ -173,8 +180,9 @@ def build_rmh():
                proposal_logdensity_fn: Optional[Callable] = None):
         transition_energy = build_rmh_transition_energy(proposal_logdensity_fn)
         ratio = compute_asymmetric_acceptance_ratio(transition_energy)
-        new_state, do_accept, p_accept, proposed = rmh_proposal(logdensity_fn, transition_generator, ratio)(rng_key, state)
-        return new_state, RWAInfo(p_accept, do_accept, proposed)
+        generate = rmh_proposal(logdensity_fn, transition_generator, ratio)
+        new_state, do_accept, p_accept = generate(rng_key, state)
+        return new_state, RWAInfo(p_accept, do_accept, new_state, generate.last_proposed)
     return kernel
 
 

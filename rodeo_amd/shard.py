@@ -2,7 +2,8 @@
 Multi-GPU: the path shards by independent trajectories / parameter draws -- one process per
 GPU, a contiguous split of the batch axis, NO collective on the data path.  The only exchange is the all-gather of
 per-trajectory scalars (e.g. the 8192 log-posteriors of BASELINE config 4), which runs over RCCL/xGMI inside
-librodeo_kalman.so (``rk_allgather_f64``) on GPUs, or over any ``torch.distributed`` backend (gloo in the CPU tests).
+librodeo_kalman.so (``rk_allgather_f64``) on GPUs, or over a host channel: ``rodeo_amd.hostgroup.HostGroup`` (standard
+library) or any ``torch.distributed`` backend (gloo in the CPU tests).
 
 Random draws are keyed by the GLOBAL trajectory index (``traj_offset`` of the C ABI), so results do not depend on the
 number of ranks.
@@ -32,12 +33,21 @@ def shard(arr, rank, nranks, batched=True):
 
 def gather_scalars(local, n_total, rank, nranks, dist=None):
     """
-    All-gather per-trajectory scalars (n_local,) -> (n_total,) in global trajectory order using a
-    ``torch.distributed`` process group (any backend; gloo in the CPU tests).  Ragged shards are padded.
+    All-gather per-trajectory scalars (n_local,) -> (n_total,) in global trajectory order over a HOST channel:
+    ``dist`` is a ``rodeo_amd.hostgroup.HostGroup`` (standard-library TCP star, what bench.py and the scripts use) or a
+    ``torch.distributed``-like module / process group (any backend; gloo in the CPU tests).  Ragged shards are fine.
+    On GPUs with an RCCL communicator use ``RcclComm.allgather`` instead (device buffers, xGMI).
     """
     local = np.ascontiguousarray(local, dtype=np.float64)
     if nranks == 1:
         return local.copy()
+    if hasattr(dist, "allgather_f64"):                    # HostGroup
+        parts = dist.allgather_f64(local)
+        for r in range(nranks):
+            lo, hi = partition(n_total, r, nranks)
+            if parts[r].shape[0] != hi - lo:
+                raise ValueError(f"rank {r} sent {parts[r].shape[0]} scalars, its shard has {hi - lo}")
+        return np.concatenate(parts)
     import torch
     import torch.distributed as tdist
     dist = dist or tdist
@@ -51,6 +61,51 @@ def gather_scalars(local, n_total, rank, nranks, dist=None):
         lo, hi = partition(n_total, r, nranks)
         parts.append(outs[r][:hi - lo].numpy())
     return np.concatenate(parts)
+
+
+def init_rccl_or_fail(device, group, deadline=90.0):
+    """
+    Bring up the RCCL communicator of ``device`` for the ranks of ``group`` (a HostGroup carries the unique id).
+    Returns ``(comm, must_hard_exit, why)``: ``comm`` is an ``RcclComm`` when EVERY rank got one, else None (all ranks
+    agree on the outcome; ``why`` then says what went wrong on this rank).  ``rk_comm_init`` runs in a helper thread
+    with a deadline; if any rank's bootstrap is stuck, ``must_hard_exit`` is True on ALL ranks: they must leave the
+    process with ``os._exit`` once their work is done (a thread is still inside RCCL) -- a stuck bootstrap must not
+    hang the job.
+    """
+    import threading
+    state = {"comm": None, "err": None}
+    uid = b""
+    if group.rank == 0:
+        buf = (C.c_char * _lib.COMM_UID_BYTES)()
+        try:
+            _lib.check(device.lib.rk_comm_uid(buf))
+            uid = bytes(buf)
+        except Exception as e:                           # noqa: BLE001
+            state["err"] = e
+    uid = group.bcast_bytes(uid, src=0)
+    stuck = False
+    if len(uid) == _lib.COMM_UID_BYTES:
+        def _init():
+            try:
+                state["comm"] = RcclComm(device, group.rank, group.world, uid=uid)
+            except Exception as e:                       # noqa: BLE001
+                state["err"] = e
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(timeout=deadline)
+        stuck = th.is_alive()
+    ok = state["comm"] is not None and not stuck
+    all_ok = group.allreduce(1 if ok else 0, "min") == 1
+    any_stuck = group.allreduce(1 if stuck else 0, "max") == 1
+    if all_ok:
+        return state["comm"], False, ""
+    if ok:
+        try:
+            state["comm"].close()
+        except Exception:                                # noqa: BLE001
+            pass
+    why = "bootstrap timed out" if stuck else (state["err"] or "another rank failed")
+    return None, bool(stuck or any_stuck), str(why)
 
 
 class RcclComm:

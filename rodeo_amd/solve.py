@@ -136,12 +136,14 @@ class SolvePlan:
         self._ws = None                    # device scratch for the dense path
         self.mean_state = self.var_state = self.mean_pred = self.var_pred = self.x_state = None
         self._out = _lib.SolveOut()
+        self.generation = 0                # bumped by every launch and every update(): lazily read results check it
 
     def update(self, ode_init=None, prior_pars=None, **params):
         """
         Replace inputs of the same shapes in place (device buffers and outputs are reused) -- what a sampler does between
         two log-density evaluations: new initial values, prior scales and ODE parameters for every trajectory.
         """
+        self.generation += 1
         if ode_init is not None:
             x0 = np.asarray(ode_init, dtype=np.float64)
             self._x0.upload(_bm(x0, x0.ndim == 3))
@@ -193,6 +195,7 @@ class SolvePlan:
 
     # ---- launches (asynchronous) ----
     def _call(self, fn, key, mode):
+        self.generation += 1               # whatever is in the output buffers now belongs to an earlier call
         self._prepare_out(mode)
         self.last_mode = mode
         self.cfg.seed = _seed(key)

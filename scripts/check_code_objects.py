@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""
+Build-time check of the gfx950 code objects inside rodeo_amd/librodeo_kalman.so (run by `make check` in
+rodeo_amd/csrc, by __graft_entry__.build() and by tests/test_abi_and_host.py): every kernel's AMDGPU metadata is read
+back with llvm-readelf and must satisfy what the launches assume, so that a resource problem shows up as a failed
+build here and not as a fault on the GPU box:
+
+  * no dynamic stack (`.uses_dynamic_stack: false`): the kernels call real device functions (dense path), whose frames
+    must be known to the compiler -- an indirect or recursive call would make the runtime guess a stack size;
+  * private segment (scratch: spills + frames of called functions) at most SCRATCH_LIMIT bytes per lane, except the
+    kernels listed in SCRATCH_ALLOW with their own bound (runtime-sized local arrays of the unit-parity path);
+  * LDS at most 160 KB (MI355X_MICROARCH.md);
+  * registers: VGPRs + AGPRs of a kernel fit the waves its own launch bound puts on one SIMD
+    (512 per SIMD lane / ceil(max_flat_workgroup_size / 256) waves).
+
+    python3 scripts/check_code_objects.py [path/to/librodeo_kalman.so]      exit code 0 = all kernels pass
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = os.environ.get("RK_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+SCRATCH_LIMIT = 2048
+SCRATCH_ALLOW = {"kalman_op_kernel": 32768}        # kalman_batched.hip: runtime (n_state <= 16) local matrices, unit-parity ops
+LDS_LIMIT = 160 * 1024
+FIELDS = ("agpr_count", "group_segment_fixed_size", "max_flat_workgroup_size", "private_segment_fixed_size",
+          "sgpr_spill_count", "uses_dynamic_stack", "vgpr_count", "vgpr_spill_count")
+
+
+def kernels_of(so_path):
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "lib.so")
+        os.symlink(os.path.abspath(so_path), local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, cwd=tmp,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, f)], check=True,
+                                 capture_output=True, text=True).stdout
+            for block in re.split(r"\n  - (?=\.agpr_count|\.args)", txt)[1:]:
+                k = {}
+                m = re.search(r"^\s+\.name:\s+(\S+)", block, re.M)
+                if not m:
+                    continue
+                k["name"] = m.group(1)
+                for fld in FIELDS:
+                    mm = re.search(r"^\s+\.%s:\s+(\S+)" % fld, block, re.M)
+                    if mm:
+                        v = mm.group(1)
+                        k[fld] = (v == "true") if v in ("true", "false") else int(v)
+                out.append(k)
+    return out
+
+
+def demangled(name):
+    try:
+        out = subprocess.run([os.path.join(LLVM, "llvm-cxxfilt"), name], capture_output=True, text=True).stdout.strip()
+        return out or name
+    except OSError:
+        return name
+
+
+def check(kernels):
+    problems = []
+    for k in kernels:
+        nm = demangled(k["name"])
+        if k.get("uses_dynamic_stack", False):
+            problems.append(f"{nm}: uses a dynamic stack")
+        lim = max([v for key, v in SCRATCH_ALLOW.items() if key in k["name"]] + [SCRATCH_LIMIT])
+        if k.get("private_segment_fixed_size", 0) > lim:
+            problems.append(f"{nm}: {k['private_segment_fixed_size']} B of scratch per lane (limit {lim})")
+        if k.get("group_segment_fixed_size", 0) > LDS_LIMIT:
+            problems.append(f"{nm}: {k['group_segment_fixed_size']} B of LDS (limit {LDS_LIMIT})")
+        wg = k.get("max_flat_workgroup_size", 1024)
+        waves_per_simd = max(1, -(-wg // 256))
+        regs = k.get("vgpr_count", 0) + k.get("agpr_count", 0)
+        if regs > 512 // waves_per_simd:
+            problems.append(f"{nm}: {regs} VGPRs+AGPRs do not fit {waves_per_simd} wave(s) per SIMD "
+                            f"(workgroup {wg})")
+    return problems
+
+
+def main():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "rodeo_amd", "librodeo_kalman.so")
+    ks = kernels_of(so)
+    if not ks:
+        print("check_code_objects: no gfx950 kernels found in", so)
+        return 2
+    problems = check(ks)
+    worst = max(ks, key=lambda k: k.get("private_segment_fixed_size", 0))
+    print(f"check_code_objects: {len(ks)} kernels; largest scratch {worst.get('private_segment_fixed_size', 0)} B "
+          f"({demangled(worst['name']).split('(')[0][:60]}); {len(problems)} problem(s)")
+    for p in problems:
+        print("  ", p)
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

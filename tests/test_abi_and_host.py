@@ -131,3 +131,24 @@ def test_unknown_kalman_type_raises_before_touching_the_device():
         ra.solve_mv(None, ra.ode.fitzhugh_nagumo, np.zeros((2, 1, 3)), np.zeros((2, 3)), 0., 1., 5,
                     ra.interrogate.interrogate_kramer, (np.zeros((2, 3, 3)),) * 2, kalman_type="cholesky",
                     theta=np.ones(3))
+
+
+def test_code_objects_fit_their_launch_assumptions():
+    """Every gfx950 kernel in the shipped library: static stack, bounded scratch, LDS <= 160 KB, registers that fit the
+    waves its launch bound puts on a SIMD (scripts/check_code_objects.py; the regression guard for the dense path's real
+    device-function calls)."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_code_objects", os.path.join(root, "scripts", "check_code_objects.py"))
+    cco = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cco)
+    ks = cco.kernels_of(os.path.join(root, "rodeo_amd", "librodeo_kalman.so"))
+    assert len(ks) > 100 and any("dense_bwd_mv_kernel" in k["name"] for k in ks)
+    assert cco.check(ks) == []
+    # the checker does flag what it is there for
+    base = {"name": "k", "uses_dynamic_stack": False, "private_segment_fixed_size": 0, "group_segment_fixed_size": 0,
+            "vgpr_count": 64, "agpr_count": 0, "max_flat_workgroup_size": 256}
+    assert cco.check([base]) == []
+    bad = [dict(base, uses_dynamic_stack=True), dict(base, private_segment_fixed_size=1 << 20),
+           dict(base, vgpr_count=300, max_flat_workgroup_size=512)]
+    assert len(cco.check(bad)) == 3

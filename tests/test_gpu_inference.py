@@ -178,6 +178,28 @@ def test_fenrir_parity(ra, name):
                             kalman_type="cubature", theta=s["theta"])
 
 
+def test_lazy_mean_goes_stale_when_fenrir_reuses_the_cached_plan(ra):
+    """basic() and fenrir() with the same configuration share one cached SolvePlan (solve.cached_plan): fenrir's forward
+    filter overwrites the smoothed moments basic() left in HBM, so an Xt that was not read before must refuse to hand out
+    numbers (SolvePlan.generation), and one that was read keeps its values."""
+    from rodeo_amd.inference.basic import GaussianObsLoglik
+    s = _setup(ra, n_steps=60, t_max=3.0, n_obs=5)
+    sd = np.sqrt(0.005)
+    n_obs = len(s["obs_times"])
+    y = s["Y"][:, :, None]
+    Dw = np.zeros((n_obs, 2, 1, 3)); Dw[..., 0] = 1.0
+    Om = np.full((n_obs, 2, 1, 1), 0.005)
+    args = (None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0., s["t_max"], s["N"], ra.interrogate.interrogate_kramer,
+            s["prior"])
+    _, read = ra.inference.basic(*args, s["Y"], s["obs_times"], GaussianObsLoglik(sd), theta=s["theta"])
+    kept = np.asarray(read).copy()
+    _, unread = ra.inference.basic(*args, s["Y"], s["obs_times"], GaussianObsLoglik(sd), theta=s["theta"])
+    ra.inference.fenrir(*args, y, s["obs_times"], Dw, Om, theta=s["theta"])
+    np.testing.assert_array_equal(np.asarray(read), kept)
+    with pytest.raises(RuntimeError):
+        np.asarray(unread)
+
+
 def test_config4_full_size_per_gpu(ra):
     """
     BASELINE.json config 4 at its per-GPU size (1024 parameter draws, FN, N=800, solve_sim + interrogate_chkrebtii,

@@ -53,7 +53,8 @@ def test_one_step_against_restatement():
     np.testing.assert_array_equal(info.is_accepted, ref[3])
     np.testing.assert_allclose(info.acceptance_rate, ref[4], rtol=1e-15)
     assert 0 < info.is_accepted.sum() < C
-    np.testing.assert_array_equal(info.proposal.position, pos + inc)
+    np.testing.assert_array_equal(info.proposed.position, pos + inc)
+    assert info.proposal is new                          # the reference's convention (pseudo_marginal.py:377)
 
 
 def test_nan_and_inf_logdensities_are_rejected_or_accepted_like_blackjax():

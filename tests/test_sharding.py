@@ -72,3 +72,59 @@ def test_sharded_equals_single_process(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     np.testing.assert_array_equal(full, _logpost_of_shard(0, 10, seed=7))
+
+
+# ---- the standard-library host channel (what bench.py / scripts use instead of torch.distributed) ----------------------
+def _hg_worker(rank, world, rdzv, q):
+    from rodeo_amd.hostgroup import HostGroup
+    g = HostGroup(rank, world, rdzv_dir=rdzv, timeout=60)
+    assert g.bcast_bytes(b"uid-%d" % rank, src=0) == b"uid-0"
+    assert g.allgather(rank * 10) == [r * 10 for r in range(world)]
+    assert g.allreduce(float(rank), "max") == world - 1 and g.allreduce(rank + 1, "min") == 1
+    g.barrier()
+    lo, hi = rs.partition(10, rank, world)
+    full = rs.gather_scalars(_logpost_of_shard(lo, hi, seed=7), 10, rank, world, g)
+    if rank == 0:
+        q.put(full)
+    g.barrier()
+    g.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_hostgroup_sharded_equals_single_process(world, tmp_path):
+    import multiprocessing
+    ctx = multiprocessing.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hg_worker, args=(r, world, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(full, _logpost_of_shard(0, 10, seed=7))
+
+
+def test_hostgroup_missing_rank_times_out(tmp_path):
+    from rodeo_amd.hostgroup import HostGroup
+    with pytest.raises(TimeoutError):
+        HostGroup(0, 2, rdzv_dir=str(tmp_path), timeout=0.5)          # rank 1 never shows up: error, not a hang
+    with pytest.raises(TimeoutError):
+        HostGroup(1, 2, rdzv_dir=str(tmp_path / "nobody"), timeout=0.5)
+
+
+def test_spawn_ranks_failed_rank_ends_the_job(tmp_path):
+    """One rank exits non-zero (a failed RCCL bootstrap in bench.py --require-rccl): the launcher terminates the others
+    by PID and reports the failure -- no hang."""
+    import sys, time
+    from rodeo_amd.hostgroup import spawn_ranks
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                      "time.sleep(120)\n")
+    t0 = time.monotonic()
+    assert spawn_ranks([sys.executable, str(script)], 3) == 3
+    assert time.monotonic() - t0 < 30
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nassert os.environ['WORLD_SIZE'] == '2' and os.path.isdir(os.environ['RK_RDZV_DIR'])\n")
+    assert spawn_ranks([sys.executable, str(ok)], 2) == 0
