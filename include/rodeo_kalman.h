@@ -153,6 +153,9 @@ typedef struct {
     double* x_state;        /* (N+1, d, p, B)                                                               */
     /* scratch for the dense large-block path: rk_solve_workspace_bytes() bytes (NULL if that returns 0)     */
     void*   workspace;
+    /* size of `workspace` in bytes: a call whose configuration needs more is refused (RK_ERR_INVALID) before */
+    /* any kernel is launched                                                                                */
+    size_t  workspace_bytes;
 } rk_solve_out;
 
 /* Output layout the fused kernels use for this configuration and call (RK_MODE_*).  The MFMA-tile kernels

@@ -46,7 +46,8 @@ class SolveIn(C.Structure):
 
 class SolveOut(C.Structure):
     _fields_ = [("mean_state", C.c_void_p), ("var_state", C.c_void_p), ("mean_pred", C.c_void_p),
-                ("var_pred", C.c_void_p), ("x_state", C.c_void_p), ("workspace", C.c_void_p)]
+                ("var_pred", C.c_void_p), ("x_state", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
 
 
 class OpCfg(C.Structure):

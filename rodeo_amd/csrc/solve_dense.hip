@@ -1136,6 +1136,14 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
 
 int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, int mode) {
     RK_REQUIRE(out->workspace, RK_ERR_INVALID, "dense path needs out->workspace (rk_solve_workspace_bytes)");
+    {
+        // every kernel below indexes the workspace by trajectory with this stride: check the caller's size on the host
+        const size_t need = dense_ws_doubles(c->n_bstate, c->n_bmeas) * (size_t)c->n_traj * sizeof(double);
+        RK_REQUIRE(out->workspace_bytes >= need, RK_ERR_INVALID,
+                   "dense path: out->workspace_bytes = %zu, this configuration needs %zu (rk_solve_workspace_bytes)",
+                   out->workspace_bytes, need);
+        RK_REQUIRE(out->mean_state && out->var_state, RK_ERR_INVALID, "dense path: null output pointer");
+    }
     DenseArgs a;
     a.B = c->n_traj; a.N = c->n_steps; a.p = c->n_bstate; a.m = c->n_bmeas; a.itg = c->interrogate;
     a.t_min = c->t_min; a.t_max = c->t_max;

@@ -188,6 +188,7 @@ class SolvePlan:
             self._ws = dev.empty((wsb.value // 8,))
         self._out = _lib.SolveOut(
             workspace=self._ws.ptr if self._ws is not None else None,
+            workspace_bytes=self._ws.nbytes if self._ws is not None else 0,
             mean_state=self.mean_state.ptr if self.mean_state is not None else None, var_state=self.var_state.ptr,
             mean_pred=self.mean_pred.ptr if self.mean_pred is not None else None,
             var_pred=self.var_pred.ptr if self.var_pred is not None else None,

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     from rodeo_amd import _lib
     assert ctypes.sizeof(_lib.SolveCfg) == 10 * 4 + 2 * 8 + 2 * 8
     assert ctypes.sizeof(_lib.SolveIn) == 5 * 16
-    assert ctypes.sizeof(_lib.SolveOut) == 6 * 8
+    assert ctypes.sizeof(_lib.SolveOut) == 7 * 8
     assert ctypes.sizeof(_lib.OpCfg) == 16
 
 
@@ -73,6 +73,9 @@ def test_ibm_init_matches_oracle_and_closed_form():
         Q, R = ra.ibm_init(0.01, p, np.array([0.1, 3.0]))
         Qo, Ro = priors.ibm_init(0.01, p, np.array([0.1, 3.0]))
         np.testing.assert_allclose(Q, Qo, rtol=4e-15); np.testing.assert_allclose(R, Ro, rtol=4e-15)
+        # reference_factorial=True: the reference's exp(gammaln(.)) route (ibm.py:21-34, 54-61), bit for bit with its restatement
+        Qr, Rr = ra.ibm_init(0.01, p, np.array([0.1, 3.0]), reference_factorial=True)
+        np.testing.assert_array_equal(Qr, Qo); np.testing.assert_array_equal(Rr, Ro)
     Q, R = ra.ibm_init(0.05, 3, np.array([[.1, .2], [.3, .4]]))          # batched sigma -> batched R
     assert Q.shape == (2, 3, 3) and R.shape == (2, 2, 3, 3)
     np.testing.assert_allclose(R[1, 0], ra.ibm_init(0.05, 3, np.array([.3]))[1][0], rtol=1e-15)

@@ -157,3 +157,44 @@ def test_square_root_vs_oracle_batch(sq):
     mf, vf = sq.update(omp, ovp, r["x"], r["a"], r["W"], LV)
     omf, ovf = osq.update(omp, ovp, r["x"], r["a"], r["W"], LV)
     np.testing.assert_allclose(mf, omf, rtol=1e-9, atol=1e-10); np.testing.assert_allclose(_sqr(vf), _sqr(ovf), rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["rodeo", "schober", "kramer", "chkrebtii"])
+@pytest.mark.parametrize("rhs", ["fitzhugh_nagumo", "lorenz63"])
+def test_standalone_interrogations_builtin_rhs(name, rhs):
+    """rk_interrogate_batched for each of the four interrogations with a built-in right-hand side (src/rodeo/
+    interrogate.py:13-115): all three outputs (wgt_meas, mean_meas, var_meas) against the oracle on a random batch; a
+    single (un-batched) call returns the reference's shapes.  The chkrebtii draw goes through the shared Philox stream,
+    addressed by (seed, step, traj_offset) exactly as the fused solver addresses it."""
+    import functools
+    import rodeo_amd as ra
+    from oracle import odes, interrogations as oi
+    rng = np.random.default_rng(77)
+    d, p, B = (2, 3, 6) if rhs == "fitzhugh_nagumo" else (3, 4, 5)
+    fun, ofun = getattr(ra.ode, rhs), getattr(odes, rhs)
+    theta0 = np.array([0.2, 0.2, 3.0]) if rhs == "fitzhugh_nagumo" else np.array([28.0, 10.0, 8.0 / 3.0])
+    theta = theta0 * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, _ = ra.utils.first_order_pad(fun, d, p)
+    mp = rng.standard_normal((B, d, p))
+    a = rng.standard_normal((B, d, p, p))
+    vp = a @ np.swapaxes(a, -1, -2) + 0.1 * np.eye(p)
+    g = getattr(ra.interrogate, "interrogate_" + name)
+    o = getattr(oi, "interrogate_" + name)
+    if name == "chkrebtii":
+        seed, step, off = 1234, 7, 3
+        g = functools.partial(g, kalman_type="standard")
+        got = g((seed, step, off), fun, W, 0.3, mp, vp, theta=theta)
+        ref = o(oi.StepKey(seed, off + np.arange(B), step), ofun, W, 0.3, mp, vp, kalman_type="standard", theta=theta)
+        tol = 1e-9                                      # sqrt / Box-Muller on the device vs NumPy
+    else:
+        got = g(None, fun, W, 0.3, mp, vp, theta=theta)
+        ref = o(None, ofun, W, 0.3, mp, vp, theta=theta)
+        tol = 1e-12
+    for x, y, shape in zip(got, ref, [(B, d, 1, p), (B, d, 1), (B, d, 1, 1)]):
+        assert x.shape == shape
+        np.testing.assert_allclose(x, np.broadcast_to(y, shape), rtol=tol, atol=tol)
+    if name != "chkrebtii":
+        one = g(None, fun, W, 0.3, mp[0], vp[0], theta=theta[0])
+        assert [x.shape for x in one] == [(d, 1, p), (d, 1), (d, 1, 1)]
+        for x, y in zip(one, got):
+            np.testing.assert_array_equal(x, y[0])
