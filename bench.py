@@ -60,13 +60,33 @@ def _cpu_model():
     return "unknown"
 
 
+def _cpu_quota():
+    """CPUs this process may use at once according to its cgroup (the GPU boxes cap a job's CPU share), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(W, x0, theta, prior, budget_s=14.0):
     """
     The reference algorithm on the host cores (SURVEY.md section 8d "CPU baseline"; the protocol of the reference's own
     examples/timings.py:28-46 -- warm-up, then the mean over repeated runs), as a bounded sample of the SAME workload:
       port   -- plain-C restatement (oracle/c, -O3 -march=native, compile-time block sizes, OpenMP over trajectories).
                 Outputs and per-thread scratch are allocated and paged in ONCE, outside the timing; only the C passes are
-                timed (omp_get_wtime inside the library).  Thread sweep {1, 8, 32, 64, 128, all}: `value` is the best.
+                timed (omp_get_wtime inside the library).  Thread sweep {1, 8, 16, 32, 64, 128, all}: `value` is the best
+                (the GPU boxes cap a job's CPU share by cgroup, reported as `cgroup_cpu_quota`: more threads than that only
+                contend, which is what a falling sweep shows).
       numpy  -- the batch-vectorised NumPy restatement (oracle/scan.py: einsum / batched solves over the 1024
                 trajectories, what vmap + XLA do), a few hundred steps of the same problem.
     Both stand in for rodeo's JAX-CPU path, which cannot run here (no jax).
@@ -80,7 +100,7 @@ def cpu_baseline(W, x0, theta, prior, budget_s=14.0):
         if os.path.exists(native):
             c_port._PATH = native
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        counts = sorted({t for t in (1, 8, 32, 64, 128, avail) if t <= avail})
+        counts = sorted({t for t in (1, 8, 16, 32, 64, 128, avail) if t <= avail})
         ts = c_port.TimedSolve("fitzhugh_nagumo", "kramer", W, x0, 0.0, T_MAX, N_STEPS, prior, theta, max_threads=avail)
         per_leg = budget_s / (len(counts) + 1)
         sweep, spent = {}, 0.0
@@ -95,7 +115,8 @@ def cpu_baseline(W, x0, theta, prior, budget_s=14.0):
         one = sweep.get("1")
         out.update({
             "value": sweep[best_nt], "cores": int(best_nt), "value_best": sweep[best_nt], "threads_best": int(best_nt),
-            "value_1thread": one, "threads_available": avail, "cpu_model": _cpu_model(),
+            "value_1thread": one, "threads_available": avail, "cgroup_cpu_quota": _cpu_quota(),
+            "cpu_model": _cpu_model(),
             "scaling_efficiency_at_best": (sweep[best_nt] / (int(best_nt) * one)) if one else None,
             "thread_sweep": sweep,
             "sample": f"solve_mv + kramer on the C2 problem ({N_STEPS} steps): repeated passes over the {N_TRAJ} "

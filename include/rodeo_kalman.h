@@ -77,6 +77,9 @@ extern "C" {
                                      block = [Sigma[i][0..2], mu[i]]; mean_state is not used (may be NULL)  */
 #define RK_LAYOUT_TILE4        3  /* n_bstate = 4 only: var_state holds (N+1, B, d, 20) doubles per block:
                                      [Sigma row-major (16) | mu (4)]; mean_state is not used (may be NULL)   */
+#define RK_LAYOUT_TILEP        4  /* blocked tile path, n_bstate = 5 .. 8: var_state holds (N+1, B, d, p*p + p) doubles per
+                                     block: [Sigma row-major (p*p) | mu (p)]; mean_state is not used (may be NULL)
+                                     (RK_LAYOUT_TILE4 is this format at p = 4)                                   */
 #define RK_LAYOUT_TRAJ_MAJOR   2  /* dense large-block path: the reference's own layout with a leading batch
                                      axis, mean_state (B, N+1, d, p), var_state (B, N+1, d, p, p)            */
 

@@ -19,7 +19,7 @@ RHS_USER_BASE = 1000
 FLAG_STORE_PRED = 1
 FLAG_BATCH_MINOR = 2
 MODE_FILTER, MODE_MV, MODE_SIM = 0, 1, 2
-LAYOUT_BATCH_MINOR, LAYOUT_TILE3, LAYOUT_TRAJ_MAJOR, LAYOUT_TILE4 = 0, 1, 2, 3
+LAYOUT_BATCH_MINOR, LAYOUT_TILE3, LAYOUT_TRAJ_MAJOR, LAYOUT_TILE4, LAYOUT_TILEP = 0, 1, 2, 3, 4
 COMM_UID_BYTES = 128
 
 

@@ -36,6 +36,7 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
     if (kind == 2) snprintf(buf, sizeof buf, "rk::interrogate_kernel<rk::UserRhsT, %d, %d>", P, itg);
     else if (kind == 3) snprintf(buf, sizeof buf, "rk::fwd_tile3_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 3
     else if (kind == 4) snprintf(buf, sizeof buf, "rk::fwd_tile4_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 4
+    else if (kind == 5) snprintf(buf, sizeof buf, "rk::fwd_tilen_kernel<rk::UserRhsT, %d, %d>", itg, P); // blocked tiles, P here = NB
     else snprintf(buf, sizeof buf, "rk::fwd_kernel<rk::UserRhsT, %d, %d, %s>", P, itg, kind == 1 ? "true" : "false");
     return buf;
 }
@@ -43,7 +44,8 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
 // compile one instantiation; returns code object in `code` and the mangled name in `lowered`
 static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<char>& code, std::string& lowered) {
     const std::string src = std::string("#include \"solve_small_kernels.hpp\"\n#include \"dual.hpp\"\n"
-                                        "#include \"solve_tile3_kernels.hpp\"\n#include \"solve_tile4_kernels.hpp\"\nnamespace rk {\n") +
+                                        "#include \"solve_tile3_kernels.hpp\"\n#include \"solve_tile4_kernels.hpp\"\n"
+                                        "#include \"solve_tilen_kernels.hpp\"\nnamespace rk {\n") +
                             u.source + "\nusing UserRhsT = " + u.type_name + ";\n}  // namespace rk\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rk_user_rhs.hip", kJitNumHeaders, kJitHeaderSources, kJitHeaderNames) !=
@@ -124,22 +126,26 @@ bool user_tile_available(const rk_solve_cfg* c, int which) {
     if (idx < 0 || idx >= (int)g_rhs.size()) return false;
     const int nb = g_rhs[idx].n_block;
     if (c->n_block != nb || c->n_bmeas != 1 || c->kalman_type != RK_KALMAN_STANDARD) return false;
-    if (nb < 1 || nb > (which == 3 ? 16 : 4)) return false;      // p = 3: up to 16 blocks (4 per wave, LDS exchange); p = 4: one wave
-    const JitCode& jc = jit_code_locked(c->rhs_id, which, c->interrogate, which);
+    if (nb < 1 || nb > (which == 4 ? 4 : 16)) return false;      // p = 3 and blocked tiles: up to 16 blocks (4 per wave, LDS exchange); p = 4: one wave
+    // which = 5: the blocked tile kernel (solve_tilen_kernels.hpp), instantiated per NB = 1 (p = 4) / 2 (p = 5 .. 8)
+    const int pkey = which == 5 ? (c->n_bstate <= 4 ? 1 : 2) : which;
+    const JitCode& jc = jit_code_locked(c->rhs_id, pkey, c->interrogate, which);
     if (jc.rc && getenv("RK_JIT_VERBOSE")) fprintf(stderr, "[rk] tile kernel not available for user rhs %d (p = %d): %s\n", c->rhs_id, which, jc.error.c_str());
     return jc.rc == RK_OK;
 }
 
 int user_forward_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int which) {
     hipFunction_t fn;
-    int rc = jit_get(h, c->rhs_id, which, c->interrogate, which, &fn);
+    const int pkey = which == 5 ? (c->n_bstate <= 4 ? 1 : 2) : which;
+    int rc = jit_get(h, c->rhs_id, pkey, c->interrogate, which, &fn);
     if (rc) return rc;
     SolveArgs args = a;
-    void* params[] = {&args, &tiles};
+    int P = c->n_bstate;
+    void* params[] = {&args, &tiles, &P};                           // (the p = 3 / p = 4 kernels take the first two)
     const int tpw = c->n_block == 3 ? 3 : 4;
     const int nw = c->n_block <= 4 ? 1 : (c->n_block + 3) / 4;     // waves per workgroup (TileWaves<D>)
     const int grid = nw == 1 ? div_up(a.B * c->n_block, tpw) : a.B;
-    LaunchTimer t(h, which == 3 ? "fwd_tile3_kernel<user>" : "fwd_tile4_kernel<user>");
+    LaunchTimer t(h, which == 3 ? "fwd_tile3_kernel<user>" : (which == 4 ? "fwd_tile4_kernel<user>" : "fwd_tilen_kernel<user>"));
     RK_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 64 * nw, 1, 1, 0, h->stream, params, nullptr));
     t.stop();
     return RK_OK;

@@ -481,6 +481,12 @@ bool tile4_supported(const rk_solve_cfg* c, int mode);
 int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
 size_t tile4_doubles(const rk_solve_cfg* c);
 
+// blocked MFMA-tile path for n_bstate = 4 .. 8 (solve_tilen.hip)
+bool tilen_supported(const rk_solve_cfg* c, int mode);
+int tilen_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, double* ws, size_t ws_bytes, int mode);
+size_t tilen_tile_doubles(const rk_solve_cfg* c);
+size_t tilen_ws_doubles(const rk_solve_cfg* c, int mode);
+
 // MFMA-tile path (solve_tile3.hip)
 bool tile3_supported(const rk_solve_cfg* c, int mode);
 int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
@@ -498,13 +504,17 @@ int rk_solve_layout(const rk_solve_cfg* c, int32_t mode, int32_t* layout) {
     RK_REQUIRE(mode >= RK_MODE_FILTER && mode <= RK_MODE_SIM, RK_ERR_INVALID, "rk_solve_layout: bad mode %d", mode);
     *layout = dense_supported(c, mode) ? RK_LAYOUT_TRAJ_MAJOR
               : (tile3_supported(c, mode) ? RK_LAYOUT_TILE3
-                 : (tile4_supported(c, mode) ? RK_LAYOUT_TILE4 : RK_LAYOUT_BATCH_MINOR));
+                 : (tile4_supported(c, mode) ? RK_LAYOUT_TILE4
+                    : (tilen_supported(c, mode) ? (c->n_bstate == 4 ? RK_LAYOUT_TILE4 : RK_LAYOUT_TILEP) : RK_LAYOUT_BATCH_MINOR)));
     return RK_OK;
 }
 
 int rk_solve_workspace_bytes(const rk_solve_cfg* c, int32_t mode, size_t* bytes) {
     RK_REQUIRE(c && bytes, RK_ERR_INVALID, "rk_solve_workspace_bytes: null argument");
-    *bytes = dense_supported(c, mode) ? dense_ws_doubles(c->n_bstate, c->n_bmeas) * (size_t)c->n_traj * sizeof(double) : 0;
+    if (dense_supported(c, mode)) *bytes = dense_ws_doubles(c->n_bstate, c->n_bmeas) * (size_t)c->n_traj * sizeof(double);
+    else if (!tile3_supported(c, mode) && !tile4_supported(c, mode) && tilen_supported(c, mode))
+        *bytes = tilen_ws_doubles(c, mode) * sizeof(double);
+    else *bytes = 0;
     return RK_OK;
 }
 
@@ -526,6 +536,12 @@ int rk_solve_sizes(const rk_solve_cfg* c, int32_t layout, size_t* mean_bytes, si
         if (var_bytes) *var_bytes = tile4_doubles(c) * sizeof(double);
         return RK_OK;
     }
+    if (layout == RK_LAYOUT_TILEP) {
+        RK_REQUIRE(c->n_bstate >= 4 && c->n_bstate <= 8, RK_ERR_INVALID, "RK_LAYOUT_TILEP needs n_bstate in 4..8");
+        if (mean_bytes) *mean_bytes = 0;
+        if (var_bytes) *var_bytes = tilen_tile_doubles(c) * sizeof(double);
+        return RK_OK;
+    }
     RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR || layout == RK_LAYOUT_TRAJ_MAJOR, RK_ERR_INVALID, "unknown layout %d", layout);
     if (mean_bytes) *mean_bytes = m;
     if (var_bytes) *var_bytes = m * c->n_bstate;
@@ -539,7 +555,9 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     if (rc) return rc;
     const bool dense = dense_supported(c, mode);
     const bool tile4 = !dense && tile4_supported(c, mode);
-    const bool tile = !dense && (tile4 || tile3_supported(c, mode));
+    const bool tile3 = !dense && !tile4 && tile3_supported(c, mode);
+    const bool tilen = !dense && !tile4 && !tile3 && tilen_supported(c, mode);
+    const bool tile = tile4 || tile3 || tilen;
     RK_REQUIRE(out && out->var_state && (tile || out->mean_state), RK_ERR_INVALID,
                "out->mean_state / var_state must not be NULL");
     if (dense) {
@@ -566,7 +584,8 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
         return sqrt_solve(h, c, a, mode);
     }
     if (tile4) return tile4_solve(h, c, a, out->var_state, mode);
-    if (tile) return tile3_solve(h, c, a, out->var_state, mode);
+    if (tile3) return tile3_solve(h, c, a, out->var_state, mode);
+    if (tilen) return tilen_solve(h, c, a, out->var_state, (double*)out->workspace, out->workspace_bytes, mode);
     rc = small_forward(h, c, a);
     if (rc) return rc;
     if (mode == 1) rc = small_backward<false>(h, c, a);
@@ -615,15 +634,15 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
                          double* logpost) {
     RK_REQUIRE(h && x_state && obs && obs_ind && logpost, RK_ERR_INVALID, "rk_gauss_obs_logpost: null argument");
     RK_REQUIRE(layout == RK_LAYOUT_BATCH_MINOR || (layout == RK_LAYOUT_TILE3 && n_bstate == 3) ||
-                   (layout == RK_LAYOUT_TILE4 && n_bstate == 4), RK_ERR_INVALID,
+                   (layout == RK_LAYOUT_TILE4 && n_bstate == 4) || (layout == RK_LAYOUT_TILEP && n_bstate >= 4), RK_ERR_INVALID,
                "rk_gauss_obs_logpost: bad layout %d for n_bstate %d", layout, n_bstate);
     RK_REQUIRE(n_traj >= 1 && n_obs >= 0 && n_block >= 1 && n_bstate >= 1 && n_steps >= 1, RK_ERR_INVALID,
                "rk_gauss_obs_logpost: bad dimension");
     RK_HIP(hipSetDevice(h->device));
     LaunchTimer t(h, "gauss_logpost_kernel");
     hipLaunchKernelGGL(gauss_logpost_kernel, dim3(div_up(n_traj, 64)), dim3(64), 0, h->stream, n_traj, n_steps, n_block,
-                       n_bstate, layout == RK_LAYOUT_TILE3 ? 12 : (layout == RK_LAYOUT_TILE4 ? 20 : 0),
-                       layout == RK_LAYOUT_TILE3 ? 3 : 16, x_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
+                       n_bstate, layout == RK_LAYOUT_TILE3 ? 12 : (layout == RK_LAYOUT_BATCH_MINOR ? 0 : n_bstate * (n_bstate + 1)),
+                       layout == RK_LAYOUT_TILE3 ? 3 : n_bstate * n_bstate, x_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
     t.stop();
     RK_HIP(hipGetLastError());
     return RK_OK;

@@ -1,0 +1,402 @@
+// Blocked MFMA-tile solver for n_bstate = 4 .. 8 (n_bmeas = 1): the general-n_deriv form of the tile path.
+//
+//   src/rodeo/solve.py:31-122   _solve_filter -> fwd_tilen_kernel        (solve_tilen_kernels.hpp) NB x NB tiles per block
+//   src/rodeo/solve.py:257-301  solve_mv      -> tilen_gain_kernel       time-parallel: one lane per (step, unit) item
+//                                                + bwd_mv_tilen_kernel   the carry recursion on blocked MFMA tiles
+//   src/rodeo/solve.py:162-204  solve_sim     -> tilen_gain_kernel<SIM>  + bwd_sim_tilen_kernel
+//
+// Why two kernels for the backward pass: the smoothing gain G_n = Sigma_f Q^T (Sigma-_{n+1})^{-1} (standard.py:175-176)
+// and, for solve_sim, the conditional factor and the normals do not depend on the carry, so they are evaluated for ALL
+// time steps at once -- one lane per (step, unit), register LU with partial pivoting like the reference's utils.py:119
+// -- into a workspace record per item; the sequential part that remains is, per step,
+//     solve_mv :  D = S_s - S- ; V = (G D)^T ; S_s = V^T G^T + Sigma_f ; m_s = G (m_s - m-) + mu_f     (standard.py:213-216)
+//     solve_sim:  x = G (x - m-) + (mu_f + L z)                                                         (standard.py:248-254)
+// on the same blocked tiles as the forward pass, with the records of the next steps loaded LOOKAHEAD steps ahead.
+// (The p = 3 / p = 4 solve_mv kernels fuse the two through LDS; at p up to 8 a chunk of records no longer fits there.)
+//
+// Workspace record of item (n, unit), RS doubles (padded to even):
+//     solve_mv :  [ G^T row-major (p*p) | Sigma-_{n+1} (p*p) | mu-_{n+1} (p) ]
+//     solve_sim:  [ G^T row-major (p*p) | mu-_{n+1} (p)      | mu_f + L z (p) ]      (n = N: G = 0, mu- = 0: the terminal draw)
+#include "common.hpp"
+#include "kalman_small.hpp"
+#include "mfma_tile.hpp"
+#include "philox.hpp"
+#include "rhs.hpp"
+#include "solve_args.hpp"
+#include "solve_tilen_kernels.hpp"
+
+namespace rk {
+
+__host__ __device__ inline int tilen_rs(int p, bool sim) {
+    const int rs = sim ? p * p + 2 * p : 2 * p * p + p;
+    return rs + (rs & 1);
+}
+
+// ---- phase 1: one lane per (step, unit) ------------------------------------------------------------------------------
+// grid = (number of steps) x ceil(n_units / 64) workgroups; block = 64 lanes = 64 consecutive units of one time step.
+template <int P, bool SIM>
+__global__ void __launch_bounds__(64) tilen_gain_kernel(SolveArgs a, const double* __restrict__ tiles, double* __restrict__ ws,
+                                                        int blocks_per_step) {
+    constexpr int PP = P * P + P;
+    const int D = a.D, n_units = a.B * D;
+    const int step_idx = blockIdx.x / blocks_per_step;
+    const int tau = (blockIdx.x - step_idx * blocks_per_step) * 64 + threadIdx.x;
+    if (tau >= n_units) return;
+    const int n = step_idx + 1;                                      // mv: 1 .. N-1 ; sim: 1 .. N
+    const int b = tau / D, blk = tau - b * D;
+    const int RS = tilen_rs(P, SIM);
+    double Q[P][P], R[P][P];
+    load_block_consts<P>(a, blk, b, Q, R);
+    double mf[P], Sf[P][P];
+    {
+        const double2* src = (const double2*)(tiles + ((size_t)n * n_units + tau) * PP);     // PP is even: 16-byte aligned
+        double buf[PP];
+#pragma unroll
+        for (int k = 0; k < PP / 2; ++k) { const double2 v = src[k]; buf[2 * k] = v.x; buf[2 * k + 1] = v.y; }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            mf[i] = buf[P * P + i];
+#pragma unroll
+            for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * P + j];
+        }
+    }
+    double* rec = ws + ((size_t)n * n_units + tau) * RS;
+    const bool term = SIM && n == a.N;                               // terminal draw x_N ~ N(filt[N]) (solve.py:182-186)
+    double mp[P], Sp[P][P], T[P][P], A[P][P], X[P][P];
+    predict_block<P>(Q, R, mf, Sf, mp, Sp);                          // pred[n+1] from filt[n]   (standard.py:57-59)
+    mm_nt<P, P, P>(Sf, Q, T);                                        // T = Sigma_f Q^T          (standard.py:175)
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j < P; ++j) { A[i][j] = Sp[i][j]; X[i][j] = T[j][i]; }
+    lu_solve<P, P>(A, X);                                            // X = solve(Sigma-, T^T) = G^T (standard.py:176)
+    if constexpr (!SIM) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            rec[2 * P * P + i] = mp[i];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                rec[i * P + j] = X[i][j];
+                rec[P * P + i * P + j] = Sp[i][j];
+            }
+        }
+    } else {
+        const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+        double z[P], G[P][P], GT[P][P], Ssim[P][P], L[P][P];
+        normals<P>(a.seed, traj, (uint32_t)n, (uint32_t)blk, PURPOSE_SMOOTH, z);
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P; ++j) G[i][j] = term ? 0.0 : X[j][i];
+        mm_nt<P, P, P>(G, T, GT);
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P; ++j) Ssim[i][j] = Sf[i][j] - GT[i][j];          // standard.py:253-254
+        psd_factor<P>(Ssim, L);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            double w = mf[i];
+#pragma unroll
+            for (int k = 0; k <= i; ++k) w = fma(L[i][k], z[k], w);
+            rec[P * P + i] = term ? 0.0 : mp[i];
+            rec[P * P + P + i] = w;                                                 // mu_f + L z
+#pragma unroll
+            for (int j = 0; j < P; ++j) rec[i * P + j] = G[j][i];                   // G^T
+        }
+    }
+}
+
+// ---- phase 2: the sequential chains on blocked tiles ---------------------------------------------------------------------
+// One wave = 4 units (lane = 16 r + 4 g + c).  LA steps of records are in flight: the loop body is unrolled CH steps with
+// all loads of step s + LA issued before the MFMAs of step s (static register names, so hipcc counts vmcnt per load).
+constexpr int TN_CH = 8, TN_LA = 3;
+
+template <int NB>
+__global__ void __launch_bounds__(64) bwd_mv_tilen_kernel(SolveArgs a, double* __restrict__ tiles, const double* __restrict__ ws, int P) {
+    const int n_units = a.B * a.D, PP = P * P + P, RS = tilen_rs(P, false);
+    const int lane = threadIdx.x, r = lane >> 4, g = (lane >> 2) & 3, c = lane & 3;
+    const int tau_raw = blockIdx.x * 4 + g;
+    const bool valid = tau_raw < n_units;
+    const int tau = valid ? tau_raw : n_units - 1;
+    // per-lane element offsets (in doubles) inside a unit's tile record / workspace record; padded entries read slot 0 and
+    // are zeroed by `in`
+    int oS[NB][NB], oM[NB], oG[NB][NB], oP[NB][NB], oMp[NB];
+    bool in[NB][NB], inv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int i = 4 * k + r;
+        inv[k] = i < P;
+        oM[k] = tau * PP + (inv[k] ? P * P + i : 0);
+        oMp[k] = tau * RS + (inv[k] ? 2 * P * P + i : 0);
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const int j = 4 * bb + c;
+            in[k][bb] = i < P && j < P;
+            const int e = in[k][bb] ? i * P + j : 0;
+            oS[k][bb] = tau * PP + e;
+            oG[k][bb] = tau * RS + e;
+            oP[k][bb] = tau * RS + P * P + e;
+        }
+    }
+    const size_t tstride = (size_t)n_units * PP, wstride = (size_t)n_units * RS;
+    // carry = filt[N] (solve.py:279-282)
+    double Ms[NB][NB], ms[NB];
+    {
+        const double* t = tiles + (size_t)a.N * tstride;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            ms[k] = inv[k] ? t[oM[k]] : 0.0;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) Ms[k][bb] = in[k][bb] ? t[oS[k][bb]] : 0.0;
+        }
+    }
+    struct Rec { double Gt[NB][NB], Sp[NB][NB], Sf[NB][NB], mp[NB], mf[NB]; };
+    auto load = [&](int n, Rec& q) {
+        const double* t = tiles + (size_t)n * tstride;
+        const double* w = ws + (size_t)n * wstride;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            q.mp[k] = w[oMp[k]];
+            q.mf[k] = t[oM[k]];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                q.Gt[k][bb] = w[oG[k][bb]];
+                q.Sp[k][bb] = w[oP[k][bb]];
+                q.Sf[k][bb] = t[oS[k][bb]];
+            }
+        }
+    };
+    auto step = [&](int n, const Rec& q) {
+        double Dm[NB][NB], dm[NB], V1[NB][NB], Gt[NB][NB], Sf[NB][NB], mf[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            dm[k] = inv[k] ? ms[k] - q.mp[k] : 0.0;
+            mf[k] = inv[k] ? q.mf[k] : 0.0;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                Dm[k][bb] = in[k][bb] ? Ms[k][bb] - q.Sp[k][bb] : 0.0;
+                Gt[k][bb] = in[k][bb] ? q.Gt[k][bb] : 0.0;
+                Sf[k][bb] = in[k][bb] ? q.Sf[k][bb] : 0.0;
+            }
+        }
+        bmm_tn0<NB>(Dm, Gt, V1);                         // (G D)^T
+        bmm_tn<NB>(V1, Gt, Sf, Ms);                      // G D G^T + Sigma_f      (standard.py:215-216)
+        bmv_t<NB>(Gt, dm, mf, ms);                       // G (m_s - m-) + mu_f    (standard.py:213-214)
+        double* t = tiles + (size_t)n * tstride;
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (inv[k] && c == 0) t[oM[k]] = ms[k];
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb)
+                    if (in[k][bb]) t[oS[k][bb]] = Ms[k][bb];
+            }
+        }
+    };
+    int n = a.N - 1;                                      // steps n = N-1 .. 1
+    while (n >= TN_CH) {                                  // a full chunk: steps n .. n - CH + 1 (all >= 1)
+        Rec q[TN_CH];
+#pragma unroll
+        for (int s = 0; s < TN_LA; ++s) load(n - s, q[s]);
+#pragma unroll
+        for (int s = 0; s < TN_CH; ++s) {
+            if (s + TN_LA < TN_CH) load(n - s - TN_LA, q[s + TN_LA]);
+            step(n - s, q[s]);
+        }
+        n -= TN_CH;
+    }
+    for (; n >= 1; --n) {
+        Rec q;
+        load(n, q);
+        step(n, q);
+    }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(64) bwd_sim_tilen_kernel(SolveArgs a, const double* __restrict__ tiles, const double* __restrict__ ws, int P) {
+    const int D = a.D, n_units = a.B * D, PP = P * P + P, RS = tilen_rs(P, true);
+    const int lane = threadIdx.x, r = lane >> 4, g = (lane >> 2) & 3, c = lane & 3;
+    const int tau_raw = blockIdx.x * 4 + g;
+    const bool valid = tau_raw < n_units;
+    const int tau = valid ? tau_raw : n_units - 1;
+    const int b = tau / D, blk = tau - b * D;
+    int oG[NB][NB], oMp[NB], oW[NB];
+    bool in[NB][NB], inv[NB];
+    size_t ox[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int i = 4 * k + r;
+        inv[k] = i < P;
+        oMp[k] = tau * RS + (inv[k] ? P * P + i : 0);
+        oW[k] = tau * RS + (inv[k] ? P * P + P + i : 0);
+        ox[k] = ((size_t)blk * P + (inv[k] ? i : 0)) * (size_t)a.B + b;          // x_state (N+1, d, p, B)
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const int j = 4 * bb + c;
+            in[k][bb] = i < P && j < P;
+            oG[k][bb] = tau * RS + (in[k][bb] ? i * P + j : 0);
+        }
+    }
+    const size_t wstride = (size_t)n_units * RS, xstride = (size_t)D * P * a.B;
+    struct Rec { double Gt[NB][NB], mp[NB], w[NB]; };
+    auto load = [&](int n, Rec& q) {
+        const double* w = ws + (size_t)n * wstride;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            q.mp[k] = w[oMp[k]];
+            q.w[k] = w[oW[k]];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) q.Gt[k][bb] = w[oG[k][bb]];
+        }
+    };
+    double x[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) x[k] = 0.0;
+    auto step = [&](int n, const Rec& q) {
+        double dx[NB], Gt[NB][NB], w[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            dx[k] = inv[k] ? x[k] - q.mp[k] : 0.0;
+            w[k] = inv[k] ? q.w[k] : 0.0;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) Gt[k][bb] = in[k][bb] ? q.Gt[k][bb] : 0.0;
+        }
+        bmv_t<NB>(Gt, dx, w, x);                         // x_n = G (x_{n+1} - mu-) + mu_f + L z   (standard.py:251-254, solve.py:179)
+        if (valid && c == 0) {
+            double* xo = a.x + (size_t)n * xstride;
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (inv[k]) xo[ox[k]] = x[k];
+        }
+    };
+    int n = a.N;                                          // steps n = N .. 1 (n = N: the terminal draw)
+    while (n >= TN_CH) {
+        Rec q[TN_CH];
+#pragma unroll
+        for (int s = 0; s < TN_LA; ++s) load(n - s, q[s]);
+#pragma unroll
+        for (int s = 0; s < TN_CH; ++s) {
+            if (s + TN_LA < TN_CH) load(n - s - TN_LA, q[s + TN_LA]);
+            step(n - s, q[s]);
+        }
+        n -= TN_CH;
+    }
+    for (; n >= 1; --n) {
+        Rec q;
+        load(n, q);
+        step(n, q);
+    }
+    // x[0] = ode_init exactly (solve.py:196-204): the mean of tile time 0
+    if (valid && c == 0) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (inv[k]) a.x[ox[k]] = tiles[(size_t)tau * PP + P * P + 4 * k + r];
+    }
+}
+
+// ---- dispatch ---------------------------------------------------------------------------------------------------
+static inline int tilen_nb(int p) { return p <= 4 ? 1 : 2; }
+
+template <class RHS, int NB>
+static int launch_fwd_tilen_nb(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles) {
+    constexpr int NW = TileWaves<RHS::D>::value;
+    const dim3 grid(NW == 1 ? div_up(a.B * RHS::D, Tpw<RHS::D>::value) : a.B), block(64 * NW);
+    const int P = c->n_bstate;
+    LaunchTimer t(h, "fwd_tilen_kernel");
+    switch (c->interrogate) {
+        case RK_INTERROGATE_KRAMER:
+            hipLaunchKernelGGL((fwd_tilen_kernel<RHS, RK_INTERROGATE_KRAMER, NB>), grid, block, 0, h->stream, a, tiles, P); break;
+        case RK_INTERROGATE_SCHOBER:
+            hipLaunchKernelGGL((fwd_tilen_kernel<RHS, RK_INTERROGATE_SCHOBER, NB>), grid, block, 0, h->stream, a, tiles, P); break;
+        case RK_INTERROGATE_RODEO:
+            hipLaunchKernelGGL((fwd_tilen_kernel<RHS, RK_INTERROGATE_RODEO, NB>), grid, block, 0, h->stream, a, tiles, P); break;
+        case RK_INTERROGATE_CHKREBTII:
+            hipLaunchKernelGGL((fwd_tilen_kernel<RHS, RK_INTERROGATE_CHKREBTII, NB>), grid, block, 0, h->stream, a, tiles, P); break;
+        default:
+            set_error("tile path: interrogate id %d not supported", c->interrogate);
+            return RK_ERR_UNSUPPORTED;
+    }
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+template <class RHS>
+static int launch_fwd_tilen(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles) {
+    return tilen_nb(c->n_bstate) == 1 ? launch_fwd_tilen_nb<RHS, 1>(h, c, a, tiles) : launch_fwd_tilen_nb<RHS, 2>(h, c, a, tiles);
+}
+
+bool is_user_rhs(int rhs_id);
+bool user_tile_available(const rk_solve_cfg* c, int which);
+int user_forward_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int which);
+
+bool tilen_supported(const rk_solve_cfg* c, int mode) {
+    if (c->flags & (RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)) return false;
+    if (c->kalman_type != RK_KALMAN_STANDARD || c->n_bmeas != 1) return false;
+    if (c->n_bstate < 4 || c->n_bstate > 8) return false;
+    if (c->interrogate < RK_INTERROGATE_RODEO || c->interrogate > RK_INTERROGATE_CHKREBTII) return false;
+    if (c->rhs_id == RK_RHS_FITZHUGH_NAGUMO) return c->n_block == 2;
+    if (c->rhs_id == RK_RHS_LORENZ63) return c->n_block == 3;
+    if (c->rhs_id == RK_RHS_HIGHER_ORDER) return c->n_block == 1;
+    if (is_user_rhs(c->rhs_id)) return user_tile_available(c, 5);       // hiprtc build of fwd_tilen_kernel (rhs_jit.hip)
+    return false;
+}
+
+size_t tilen_tile_doubles(const rk_solve_cfg* c) {
+    const size_t pp = (size_t)c->n_bstate * (c->n_bstate + 1);
+    return (size_t)(c->n_steps + 1) * c->n_block * (size_t)c->n_traj * pp;
+}
+
+size_t tilen_ws_doubles(const rk_solve_cfg* c, int mode) {
+    if (mode == RK_MODE_FILTER) return 0;
+    return (size_t)(c->n_steps + 1) * c->n_block * (size_t)c->n_traj * tilen_rs(c->n_bstate, mode == RK_MODE_SIM);
+}
+
+int tilen_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, double* ws, size_t ws_bytes, int mode) {
+    const int P = c->n_bstate, n_units = a.B * a.D;
+    RK_REQUIRE((size_t)n_units * (size_t)P * (P + 1) < 0x7fffffffull && (size_t)n_units * tilen_rs(P, mode == RK_MODE_SIM) < 0x7fffffffull,
+               RK_ERR_UNSUPPORTED, "blocked tile path: n_traj * n_block too large for 32-bit record offsets");
+    if (mode != RK_MODE_FILTER) {
+        const size_t need = tilen_ws_doubles(c, mode) * sizeof(double);
+        RK_REQUIRE(ws && ws_bytes >= need, RK_ERR_INVALID,
+                   "blocked tile path: out->workspace_bytes = %zu, this call needs %zu (rk_solve_workspace_bytes)", ws_bytes, need);
+    }
+    int rc;
+    if (c->rhs_id == RK_RHS_FITZHUGH_NAGUMO) rc = launch_fwd_tilen<FitzHughNagumo>(h, c, a, tiles);
+    else if (c->rhs_id == RK_RHS_LORENZ63) rc = launch_fwd_tilen<Lorenz63>(h, c, a, tiles);
+    else if (is_user_rhs(c->rhs_id)) rc = user_forward_tile(h, c, a, tiles, 5);
+    else rc = launch_fwd_tilen<HigherOrder>(h, c, a, tiles);
+    if (rc || mode == RK_MODE_FILTER) return rc;
+    const bool sim = mode == RK_MODE_SIM;
+    const int n_items_t = sim ? a.N : a.N - 1;            // time steps with an item: n = 1 .. N (sim) / N-1 (mv)
+    if (n_items_t >= 1) {
+        const int bps = div_up(n_units, 64);
+        RK_REQUIRE((size_t)bps * (size_t)n_items_t < 0x7fffffffull, RK_ERR_UNSUPPORTED,
+                   "blocked tile path: n_steps * n_traj * n_block too large for one launch");
+        const dim3 grid((unsigned)(bps * n_items_t)), block(64);
+        LaunchTimer t(h, sim ? "tilen_gain_kernel<sim>" : "tilen_gain_kernel");
+#define RK_GAIN(P_)                                                                                     \
+    case P_:                                                                                            \
+        if (sim) hipLaunchKernelGGL((tilen_gain_kernel<P_, true>), grid, block, 0, h->stream, a, tiles, ws, bps);   \
+        else hipLaunchKernelGGL((tilen_gain_kernel<P_, false>), grid, block, 0, h->stream, a, tiles, ws, bps);      \
+        break;
+        switch (P) { RK_GAIN(4) RK_GAIN(5) RK_GAIN(6) RK_GAIN(7) RK_GAIN(8) }
+#undef RK_GAIN
+        t.stop();
+        RK_HIP(hipGetLastError());
+    }
+    const dim3 grid(div_up(n_units, 4)), block(64);
+    LaunchTimer t(h, sim ? "bwd_sim_tilen_kernel" : "bwd_mv_tilen_kernel");
+    if (sim) {
+        if (tilen_nb(P) == 1) hipLaunchKernelGGL((bwd_sim_tilen_kernel<1>), grid, block, 0, h->stream, a, tiles, ws, P);
+        else hipLaunchKernelGGL((bwd_sim_tilen_kernel<2>), grid, block, 0, h->stream, a, tiles, ws, P);
+    } else if (a.N >= 2) {
+        if (tilen_nb(P) == 1) hipLaunchKernelGGL((bwd_mv_tilen_kernel<1>), grid, block, 0, h->stream, a, tiles, ws, P);
+        else hipLaunchKernelGGL((bwd_mv_tilen_kernel<2>), grid, block, 0, h->stream, a, tiles, ws, P);
+    }
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
+}  // namespace rk

@@ -73,6 +73,8 @@ def basic(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate
             rows.append(plan.var_state.slice0_host(int(n))[..., 3])            # (B, d, 3) means
         elif plan.layout == _lib.LAYOUT_TILE4:
             rows.append(plan.var_state.slice0_host(int(n))[..., 16:])          # (B, d, 4) means
+        elif plan.layout == _lib.LAYOUT_TILEP:
+            rows.append(plan.var_state.slice0_host(int(n))[..., plan.p * plan.p:])   # (B, d, p) means
         elif plan.layout == _lib.LAYOUT_TRAJ_MAJOR:
             rows.append(plan.mean_state.to_host()[:, int(n)])
         else:

@@ -38,7 +38,7 @@ def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10
         state, layout = plan.x_state, _lib.LAYOUT_BATCH_MINOR
     else:
         layout = plan.layout
-        state = plan.var_state if layout in (_lib.LAYOUT_TILE3, _lib.LAYOUT_TILE4) else plan.mean_state
+        state = plan.var_state if layout in (_lib.LAYOUT_TILE3, _lib.LAYOUT_TILE4, _lib.LAYOUT_TILEP) else plan.mean_state
     # observations / indices / output live on the plan and are re-uploaded only when they change (a pseudo-marginal
     # chain calls this once per step with the same data): per call one upload (upars) and one kernel
     cache = plan.__dict__.setdefault("_logpost_cache", {})

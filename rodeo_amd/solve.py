@@ -172,6 +172,8 @@ class SolvePlan:
                 mb, vb = C.c_size_t(0), C.c_size_t(0)
                 _lib.check(dev.lib.rk_solve_sizes(C.byref(self.cfg), lay, C.byref(mb), C.byref(vb)))
                 self._bufs[lay] = (None, dev.empty((N1, B, d, 20), pad_bytes=vb.value - N1 * B * d * 160))
+            elif lay == _lib.LAYOUT_TILEP:                                   # blocked tiles, n_bstate = 5 .. 8: [Sigma | mu]
+                self._bufs[lay] = (None, dev.empty((N1, B, d, p * p + p)))
             elif lay == _lib.LAYOUT_TRAJ_MAJOR:
                 self._bufs[lay] = (dev.empty((B, N1, d, p)), dev.empty((B, N1, d, p, p)))
             else:
@@ -228,6 +230,11 @@ class SolvePlan:
         if self.layout == _lib.LAYOUT_TILE4:
             t = np.moveaxis(self.var_state.to_host(), 1, 0)         # (B, N+1, d, 20): [Sigma (16) | mu (4)]
             mean, var = t[..., 16:], t[..., :16].reshape(t.shape[:-1] + (4, 4))
+            return (mean, var) if self.batched else (mean[0], var[0])
+        if self.layout == _lib.LAYOUT_TILEP:
+            p = self.p
+            t = np.moveaxis(self.var_state.to_host(), 1, 0)         # (B, N+1, d, p*p + p): [Sigma row-major | mu]
+            mean, var = t[..., p * p:], t[..., :p * p].reshape(t.shape[:-1] + (p, p))
             return (mean, var) if self.batched else (mean[0], var[0])
         if self.layout == _lib.LAYOUT_TRAJ_MAJOR:                    # already the reference layout
             mean, var = self.mean_state.to_host(), self.var_state.to_host()

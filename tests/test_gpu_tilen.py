@@ -1,0 +1,242 @@
+"""
+GPU parity of the BLOCKED MFMA-tile path (rodeo_amd/csrc/solve_tilen*.h*): n_bstate = 4 .. 8 -- the reference treats
+n_deriv as a free argument (src/rodeo/solve.py:48, prior/ibm.py:65-88) -- for solve_mv, the filter, solve_sim and all four
+interrogations, against the NumPy oracle on identical seeded inputs, through the C ABI.
+
+Tolerances.  The IBM prior's conditioning worsens quickly with n_deriv: a 1e-13 relative perturbation of the prior
+variance moves the ORACLE's own smoothed means by 4e-11 (p = 5) .. 5e-10 (p = 8) and its variances by up to 8e-8 (p = 8,
+kramer) on the problems below, i.e. rounding differences between two correct implementations are amplified 1e3 .. 1e6
+times.  The bounds are therefore stated per n_deriv (TOL_MEAN / TOL_VAR, relative to the scale of each derivative order
+/ of the largest variance); with p = 7, 8 the covariance-form recursion of the reference is itself unstable on longer
+horizons (the oracle overflows on FitzHugh-Nagumo beyond t = 1 at dt = 0.02), so those use a short horizon.
+"""
+import functools
+import numpy as np
+import pytest
+from oracle import scan, odes, priors, interrogations as oi
+
+pytestmark = pytest.mark.gpu
+
+TOL_MEAN = {4: 1e-9, 5: 1e-8, 6: 1e-7, 7: 1e-6, 8: 1e-5}
+TOL_VAR = {4: 1e-8, 5: 1e-7, 6: 1e-6, 7: 1e-5, 8: 1e-4}
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rodeo_amd
+    return rodeo_amd
+
+
+def _itg(ra, name):
+    g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+    if name == "chkrebtii":
+        g, o = functools.partial(g, kalman_type="standard"), functools.partial(o, kalman_type="standard")
+    return g, o
+
+
+def _fitz(ra, p, B=None, seed=0, N=50, t_max=0.5, sigma=0.1):
+    theta = np.array([0.2, 0.2, 3.0])
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0v = np.array([-1., 1.])
+    if B is not None:
+        rng = np.random.default_rng(seed)
+        theta = theta * np.exp(0.1 * rng.standard_normal((B, 3)))
+        x0v = x0v + 0.1 * rng.standard_normal((B, 2))
+    x0 = init(x0v, 0.0, theta=theta)
+    return dict(W=W, x0=x0, theta=theta, prior=ra.ibm_init(t_max / N, p, np.array([sigma] * 2)), N=N, t_max=t_max)
+
+
+def _close(m, mo, v, vo, p):
+    scale = np.maximum(np.max(np.abs(mo), axis=tuple(range(mo.ndim - 1))), 1.0)        # per derivative order
+    em = np.max(np.abs(m - mo) / scale)
+    ev = np.max(np.abs(v - vo)) / np.max(np.abs(vo))
+    assert em < TOL_MEAN[p] and ev < TOL_VAR[p], (p, em, ev)
+    return em, ev
+
+
+def _plan_layout(ra, p):
+    from rodeo_amd import _lib
+    return _lib.LAYOUT_TILE4 if p == 4 else _lib.LAYOUT_TILEP
+
+
+@pytest.mark.parametrize("p", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("name", ["kramer", "rodeo", "schober"])
+def test_blocked_tiles_solve_mv_fitzhugh(ra, p, name):
+    g, o = _itg(ra, name)
+    s = _fitz(ra, p, B=5, seed=p) if p >= 7 else _fitz(ra, p, B=5, seed=p, N=60, t_max=1.2)
+    args = (s["W"], s["x0"], 0.0, s["t_max"], s["N"])
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    plan.mv(None)
+    m, v = plan.state_host()
+    if p >= 5:                                          # p = 4 solve_mv has its own hand-trimmed kernels (solve_tile4.hip)
+        assert plan.layout == _plan_layout(ra, p)
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    assert m.shape == (5, s["N"] + 1, 2, p) and v.shape == (5, s["N"] + 1, 2, p, p)
+    _close(m, mo, v, vo, p)
+    np.testing.assert_array_equal(m[:, 0], s["x0"])
+    assert np.all(v[:, 0] == 0)
+
+
+@pytest.mark.parametrize("p", [5, 6])
+def test_blocked_tiles_kernels_are_the_ones_that_run(ra, p):
+    s = _fitz(ra, p, B=3, N=20, t_max=0.4)
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, s["t_max"], s["N"], ra.interrogate.interrogate_kramer,
+                        s["prior"], theta=s["theta"])
+    plan.dev.profile_enable(True)
+    plan.mv(None)
+    names = [k for k, _ in plan.dev.profile_last()]
+    plan.dev.profile_enable(False)
+    assert names == ["fwd_tilen_kernel", "tilen_gain_kernel", "bwd_mv_tilen_kernel"], names
+
+
+@pytest.mark.parametrize("p,rhs", [(5, "lorenz63"), (6, "lorenz63"), (6, "higher_order"), (8, "higher_order")])
+def test_blocked_tiles_other_block_counts(ra, p, rhs):
+    """n_block = 3 (one trajectory per wave, three units) and n_block = 1 (four trajectories per wave)."""
+    B = 6
+    rng = np.random.default_rng(p)
+    if rhs == "lorenz63":
+        theta = np.array([28., 10., 8. / 3.]) * np.exp(0.01 * rng.standard_normal((B, 3)))
+        W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, p)
+        x0 = init(np.array([-12., -5., 38.]) + 0.1 * rng.standard_normal((B, 3)), 0.0, theta=theta)
+        N, t_max, prior = 60, 0.06, ra.ibm_init(1e-3, p, np.array([5e7] * 3))
+        fun, ofun, kw = ra.ode.lorenz63, odes.lorenz63, dict(theta=theta)
+    else:
+        W = np.zeros((1, 1, p)); W[0, 0, 2] = 1.0
+        x0 = np.zeros((B, 1, p)); x0[:, 0, :4] = np.array([-1., 0., 1., 0.]) + 0.01 * rng.standard_normal((B, 4))
+        N, t_max, prior = 40, 2.0, ra.ibm_init(0.05, p, np.array([.001]))
+        fun, ofun, kw = ra.ode.higher_order, odes.higher_order, {}
+    for name in ("kramer", "rodeo"):
+        g, o = _itg(ra, name)
+        m, v = ra.solve_mv(None, fun, W, x0, 0.0, t_max, N, g, prior, **kw)
+        mo, vo = scan.solve_mv(None, ofun, W, x0, 0.0, t_max, N, o, prior, **kw)
+        _close(m, mo, v, vo, p)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 9, 10, 16, 17, 25])
+@pytest.mark.parametrize("B", [1, 3])
+def test_blocked_tiles_short_horizons_and_ragged_batches(ra, N, B):
+    """Around the backward chunk size (8 steps, 3 in flight) and with unit counts that do not fill a wave."""
+    p = 5
+    s = _fitz(ra, p, B=B, seed=N, N=N, t_max=0.01 * N)
+    args = (s["W"], s["x0"], 0.0, s["t_max"], N)
+    m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, s["prior"], theta=s["theta"])
+    _close(m, mo, v, vo, p)
+    x = ra.solve_sim(5, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_rodeo, s["prior"], theta=s["theta"])
+    xo = scan.solve_sim(5, odes.fitzhugh_nagumo, *args, oi.interrogate_rodeo, s["prior"], theta=s["theta"])
+    assert x.shape == xo.shape
+    scale = np.maximum(np.max(np.abs(xo), axis=tuple(range(xo.ndim - 1))), 1.0)
+    assert np.max(np.abs(x - xo) / scale) < 1e-6
+
+
+@pytest.mark.parametrize("p", [4, 5, 6])
+@pytest.mark.parametrize("name", ["rodeo", "chkrebtii", "kramer"])
+def test_blocked_tiles_solve_sim(ra, p, name):
+    """solve_sim (solve.py:125-205): forward pass (with interrogate_chkrebtii's draws inside it), backward sampler.  Device
+    and oracle share the Philox stream, so the sample paths agree to rounding (times the amplification above)."""
+    g, o = _itg(ra, name)
+    s = _fitz(ra, p, B=6, seed=10 + p, N=60, t_max=1.2)
+    args = (s["W"], s["x0"], 0.0, s["t_max"], s["N"])
+    x = ra.solve_sim(77, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    xo = scan.solve_sim(77, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    assert x.shape == (6, 61, 2, p)
+    scale = np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1.0)
+    err = np.max(np.abs(x - xo) / scale)
+    assert err < 100 * TOL_MEAN[p], err                # the psd factor of a nearly singular conditional variance
+    np.testing.assert_array_equal(x[:, 0], s["x0"])
+    # draws are keyed by the global trajectory index: the second half of the batch alone gives the same paths
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, s["W"], s["x0"][3:], 0.0, s["t_max"], s["N"], g, s["prior"], traj_offset=3,
+                        theta=s["theta"][3:])
+    plan.sim(77)
+    np.testing.assert_array_equal(plan.x_host(), x[3:])
+
+
+@pytest.mark.parametrize("p", [5, 7])
+def test_blocked_tiles_filter_and_mv_with_chkrebtii(ra, p):
+    """The filter alone (SolvePlan.filter) and solve_mv with interrogate_chkrebtii (draws inside the forward pass)."""
+    g, o = _itg(ra, "chkrebtii")
+    s = _fitz(ra, p, B=4, seed=p)
+    args = (s["W"], s["x0"], 0.0, s["t_max"], s["N"])
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    plan.filter(9)
+    mf, vf = plan.state_host()
+    ref = scan.solve_filter(9, odes.fitzhugh_nagumo, *args, o, *s["prior"], theta=s["theta"])
+    _close(mf, ref["state_filt"][0], vf, ref["state_filt"][1], p)
+    plan.mv(9)
+    m, v = plan.state_host()
+    mo, vo = scan.solve_mv(9, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    _close(m, mo, v, vo, p)
+
+
+def test_blocked_tiles_basic_and_logposterior_read_the_tile_layout(ra):
+    from scipy.stats import norm
+    from rodeo_amd.inference.basic import GaussianObsLoglik
+    p = 5
+    s = _fitz(ra, p, B=4, seed=1, N=60, t_max=1.2)
+    obs_times = np.array([0.0, 0.4, 0.8, 1.2])
+    Y = np.array([-1., 1.]) + 0.05 * np.random.default_rng(3).standard_normal((4, 2))
+    sd = 0.1
+    ll, Xt = ra.inference.basic(None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, s["t_max"], s["N"],
+                                ra.interrogate.interrogate_kramer, s["prior"], Y, obs_times, GaussianObsLoglik(sd),
+                                theta=s["theta"])
+    mo, _ = scan.solve_mv(None, odes.fitzhugh_nagumo, s["W"], s["x0"], 0.0, s["t_max"], s["N"], oi.interrogate_kramer,
+                          s["prior"], theta=s["theta"])
+    ind = np.searchsorted(np.linspace(0, s["t_max"], s["N"] + 1), obs_times)
+    ref = np.array([np.sum(norm.logpdf(Y, loc=mo[b][ind, :, 0], scale=sd)) for b in range(4)])
+    np.testing.assert_allclose(ll, ref, rtol=1e-7, atol=1e-7)
+    scale = np.maximum(np.max(np.abs(mo), axis=(0, 1, 2)), 1.0)                      # per derivative order
+    assert np.max(np.abs(np.asarray(Xt) - mo) / scale) < TOL_MEAN[p]
+    # an arbitrary Python obs_loglik: only the observed time slices come back
+    ll2, _ = ra.inference.basic(None, ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, s["t_max"], s["N"],
+                                ra.interrogate.interrogate_kramer, s["prior"], Y, obs_times,
+                                lambda obs, ode, **kw: np.sum(norm.logpdf(obs, loc=ode[:, :, 0], scale=sd)), theta=s["theta"])
+    np.testing.assert_allclose(ll2, ref, rtol=1e-7, atol=1e-7)
+
+
+def test_blocked_tiles_traced_python_rhs(ra):
+    """An ordinary Python ode_fun at n_deriv = 5 and 6: traced, compiled with hiprtc, on the blocked tile kernels
+    (two variables: one wave carries two trajectories; six variables: a two-wave workgroup per trajectory)."""
+    from rodeo_amd import _lib
+
+    def fitz(X, t, theta):
+        a, b, c = theta
+        V, R = X[0, 0], X[1, 0]
+        return np.array([[c * (V - V * V * V / 3 + R)], [-1 / c * (V - a + b * R)]])
+
+    for p in (5, 6):
+        s = _fitz(ra, p, B=5, seed=p, N=40, t_max=0.8)
+        args = (s["W"], s["x0"], 0.0, s["t_max"], s["N"])
+        plan = ra.SolvePlan(fitz, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
+        plan.mv(None)
+        assert plan.layout == _lib.LAYOUT_TILEP
+        m, v = plan.state_host()
+        mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, s["prior"], theta=s["theta"])
+        _close(m, mo, v, vo, p)
+    # six variables (the user ODE of test_gpu_user_rhs.py, Jacobian by duals) at n_deriv = 5
+    from test_gpu_user_rhs import SIX_SRC, _six_host
+    six = ra.ode.from_source("AutoJac<Six>", SIX_SRC, 6, (("theta", 4),), _six_host, name="six_p5")
+
+    def jac(X, t, theta):
+        th = np.asarray(theta, dtype=np.float64)
+        b, k, g, d = th[..., 0], th[..., 1], th[..., 2], th[..., 3]
+        I, A = X[..., 2, 0], X[..., 4, 0]
+        J = np.zeros(np.broadcast_shapes(X.shape[:-2], th.shape[:-1]) + (6, 1, X.shape[-1]))
+        J[..., 0, 0, 0] = -b * (I + 0.5 * A)
+        J[..., 1, 0, 0] = -k
+        J[..., 2, 0, 0] = -(g + d)
+        J[..., 4, 0, 0] = -g
+        J[..., 5, 0, 0] = -0.2
+        return J
+    o_ode = odes.ODE("six", 6, 1, lambda X, t, theta: _six_host(X, t, theta), jac)
+    p, B, N = 5, 3, 40
+    rng = np.random.default_rng(6)
+    theta = np.array([2.0, 0.7, 0.3, 0.1]) * np.exp(0.05 * rng.standard_normal((B, 4)))
+    W, init = ra.utils.first_order_pad(six, 6, p)
+    x0 = init(np.array([0.9, 0.04, 0.03, 0.0, 0.03, 0.0]) + 0.005 * rng.standard_normal((B, 6)), 0.0, theta=theta)
+    prior = ra.ibm_init(0.8 / N, p, np.array([.1] * 6))
+    plan = ra.SolvePlan(six, W, x0, 0., 0.8, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
+    plan.mv(None)
+    assert plan.layout == _lib.LAYOUT_TILEP
+    m, v = plan.state_host()
+    mo, vo = scan.solve_mv(None, o_ode, W, x0, 0., 0.8, N, oi.interrogate_kramer, prior, theta=theta)
+    _close(m, mo, v, vo, p)

@@ -74,11 +74,12 @@ def test_user_sir_autodiff_vs_oracle(ra):
 
 def test_user_rhs_takes_the_tile_path_when_it_can(ra):
     """User right-hand sides get the MFMA-tile forward kernels by hiprtc when the tile path supports their shape
-    (p = 3 with <= 2 blocks, p = 4 with <= 3 blocks, NDEP == 1); otherwise the lane-per-trajectory kernels."""
+    (p = 3 and the blocked tiles at p >= 5 with up to 16 blocks, p = 4 with <= 4 blocks, NDEP == 1); otherwise -- and whenever
+    RK_FLAG_BATCH_MINOR asks for it -- the lane-per-trajectory kernels."""
     from rodeo_amd import _lib
     my = ra.ode.from_source("MyFitz", FN_SRC, 2, (("theta", 3),), ra.ode.fitzhugh_nagumo._host_fun, name="myfitz_tile")
     theta = np.array([.2, .2, 3.])
-    for p, lay in ((3, _lib.LAYOUT_TILE3), (4, _lib.LAYOUT_TILE4), (5, _lib.LAYOUT_BATCH_MINOR)):
+    for p, lay in ((3, _lib.LAYOUT_TILE3), (4, _lib.LAYOUT_TILE4), (5, _lib.LAYOUT_TILEP)):
         W, init = ra.utils.first_order_pad(my, 2, p)
         x0 = init(np.array([-1., 1.]), 0.0, theta=theta)
         prior = ra.ibm_init(0.05, p, np.array([.1, .1]))
@@ -88,6 +89,11 @@ def test_user_rhs_takes_the_tile_path_when_it_can(ra):
         m, v = plan.state_host()
         mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, W, x0, 0., 2., 40, oi.interrogate_kramer, prior, theta=theta)
         assert np.max(np.abs(m - mo)) < 1e-9 * max(1.0, np.max(np.abs(mo)))
+        if p == 5:                                      # the same call forced onto the lane-per-trajectory kernels
+            pb = ra.SolvePlan(my, W, x0, 0., 2., 40, ra.interrogate.interrogate_kramer, prior, batch_minor=True, theta=theta)
+            pb.mv(None)
+            assert pb.layout == _lib.LAYOUT_BATCH_MINOR
+            assert np.max(np.abs(pb.state_host()[0] - mo)) < 1e-9 * max(1.0, np.max(np.abs(mo)))
     sir = ra.ode.from_source("AutoJac<Sir3>", SEIR_SRC, 3, (("theta", 2),), sir_host, name="sir3_tile")
     W, init = ra.utils.first_order_pad(sir, 3, 3)
     x0 = init(np.array([0.95, 0.05, 0.0]), 0.0, theta=np.array([1.5, 0.4]))
