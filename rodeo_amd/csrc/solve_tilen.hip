@@ -34,21 +34,52 @@ __host__ __device__ inline int tilen_rs(int p, bool sim) {
 
 // ---- phase 1: one lane per (step, unit) ------------------------------------------------------------------------------
 // grid = (number of steps) x ceil(n_units / 64) workgroups; block = 64 lanes = 64 consecutive units of one time step.
+// The 64 input tiles and the 64 output records of a wave are contiguous in HBM, so both pass through LDS: coalesced
+// 512-byte rows on the memory side, one record per lane (odd stride: two-way bank conflicts at most) on the register
+// side -- lane-strided global accesses touch 64 cache lines per instruction.
 template <int P, bool SIM>
 __global__ void __launch_bounds__(64) tilen_gain_kernel(SolveArgs a, const double* __restrict__ tiles, double* __restrict__ ws,
                                                         int blocks_per_step) {
     constexpr int PP = P * P + P;
-    const int D = a.D, n_units = a.B * D;
+    constexpr int RS0 = SIM ? P * P + 2 * P : 2 * P * P + P, RS = RS0 + (RS0 & 1);
+    constexpr bool STAGED = P <= 6;                                  // beyond that the staging registers only add spills (measured)
+    constexpr int LP = PP | 1, LR = RS | 1, LMAX = STAGED ? (LP > LR ? LP : LR) : 1;
+    __shared__ double sh[64 * LMAX];
+    const int D = a.D, n_units = a.B * D, lane = threadIdx.x;
     const int step_idx = blockIdx.x / blocks_per_step;
-    const int tau = (blockIdx.x - step_idx * blocks_per_step) * 64 + threadIdx.x;
-    if (tau >= n_units) return;
+    const int tau0 = (blockIdx.x - step_idx * blocks_per_step) * 64;
+    const int n_here = n_units - tau0 < 64 ? n_units - tau0 : 64;
     const int n = step_idx + 1;                                      // mv: 1 .. N-1 ; sim: 1 .. N
+    const bool live = lane < n_here;
+    const int tau = live ? tau0 + lane : n_units - 1;
     const int b = tau / D, blk = tau - b * D;
-    const int RS = tilen_rs(P, SIM);
+    if constexpr (STAGED) {
+        // (all PP loads are issued before the first LDS store: a rolled loop would wait for every load in turn)
+        const double* src = tiles + ((size_t)n * n_units + tau0) * PP;
+        const int cnt = n_here * PP;
+        double tmp[PP];
+#pragma unroll
+        for (int k = 0; k < PP; ++k) { const int i = lane + 64 * k; tmp[k] = src[i < cnt ? i : cnt - 1]; }
+#pragma unroll
+        for (int k = 0; k < PP; ++k) {
+            const int i = lane + 64 * k;
+            if (i < cnt) sh[(i / PP) * LP + (i % PP)] = tmp[k];
+        }
+        __syncthreads();
+    }
     double Q[P][P], R[P][P];
     load_block_consts<P>(a, blk, b, Q, R);
     double mf[P], Sf[P][P];
-    {
+    if constexpr (STAGED) {
+        const double* my = sh + (live ? lane : 0) * LP;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            mf[i] = my[P * P + i];
+#pragma unroll
+            for (int j = 0; j < P; ++j) Sf[i][j] = my[i * P + j];
+        }
+        __syncthreads();                                             // the staging area is reused for the records
+    } else {
         const double2* src = (const double2*)(tiles + ((size_t)n * n_units + tau) * PP);     // PP is even: 16-byte aligned
         double buf[PP];
 #pragma unroll
@@ -60,7 +91,8 @@ __global__ void __launch_bounds__(64) tilen_gain_kernel(SolveArgs a, const doubl
             for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * P + j];
         }
     }
-    double* rec = ws + ((size_t)n * n_units + tau) * RS;
+    double* rec = STAGED ? sh + lane * LR : ws + ((size_t)n * n_units + tau) * RS;
+    if (!STAGED && !live) return;
     const bool term = SIM && n == a.N;                               // terminal draw x_N ~ N(filt[N]) (solve.py:182-186)
     double mp[P], Sp[P][P], T[P][P], A[P][P], X[P][P];
     predict_block<P>(Q, R, mf, Sf, mp, Sp);                          // pred[n+1] from filt[n]   (standard.py:57-59)
@@ -105,112 +137,135 @@ __global__ void __launch_bounds__(64) tilen_gain_kernel(SolveArgs a, const doubl
             for (int j = 0; j < P; ++j) rec[i * P + j] = G[j][i];                   // G^T
         }
     }
+    if constexpr (RS != RS0) rec[RS0] = 0.0;                         // the padding double
+    if constexpr (STAGED) {
+        __syncthreads();
+        double* dst = ws + ((size_t)n * n_units + tau0) * RS;
+        const int cnt = n_here * RS;
+#pragma unroll 8
+        for (int k = 0; k < RS; ++k) {
+            const int i = lane + 64 * k;
+            if (i < cnt) dst[i] = sh[(i / RS) * LR + (i % RS)];
+        }
+    }
 }
 
 // ---- phase 2: the sequential chains on blocked tiles ---------------------------------------------------------------------
-// One wave = 4 units (lane = 16 r + 4 g + c).  LA steps of records are in flight: the loop body is unrolled CH steps with
-// all loads of step s + LA issued before the MFMAs of step s (static register names, so hipcc counts vmcnt per load).
-constexpr int TN_CH = 8, TN_LA = 3;
+// One wave = 4 units (lane = 16 r + 4 g + c).  The records of the next TN_RING - 1 steps are always in flight (static
+// register names in a fully unrolled ring, so hipcc counts vmcnt per load and the loop-carried slots need no copies).
+// All accesses are raw buffer loads / stores on a window over the wave's four units of one time row: lanes of the zero
+// padding (and of units past the end) carry an out-of-range offset, so their loads return 0.0 and their stores are
+// dropped -- no selects and no exec-mask branches in the step.
+constexpr int TN_RING = 8;
+constexpr int TN_OOR = (int)0x80000000;
+
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t rs, int off) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+    double d;
+    __builtin_memcpy(&d, &v, 8);
+    return d;
+}
+__device__ __forceinline__ void buf_st(double d, __amdgpu_buffer_rsrc_t rs, int off) {
+    u32x2 v;
+    __builtin_memcpy(&v, &d, 8);
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_window(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
 
 template <int NB>
 __global__ void __launch_bounds__(64) bwd_mv_tilen_kernel(SolveArgs a, double* __restrict__ tiles, const double* __restrict__ ws, int P) {
     const int n_units = a.B * a.D, PP = P * P + P, RS = tilen_rs(P, false);
     const int lane = threadIdx.x, r = lane >> 4, g = (lane >> 2) & 3, c = lane & 3;
-    const int tau_raw = blockIdx.x * 4 + g;
-    const bool valid = tau_raw < n_units;
-    const int tau = valid ? tau_raw : n_units - 1;
-    // per-lane element offsets (in doubles) inside a unit's tile record / workspace record; padded entries read slot 0 and
-    // are zeroed by `in`
-    int oS[NB][NB], oM[NB], oG[NB][NB], oP[NB][NB], oMp[NB];
-    bool in[NB][NB], inv[NB];
+    const bool valid = blockIdx.x * 4 + g < n_units;
+    // per-lane byte offsets inside the wave's window of a tile row (4 PP doubles) / a workspace row (4 RS doubles)
+    int oS[NB][NB], oM[NB], oMst[NB], oG[NB][NB], oP[NB][NB], oMp[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int i = 4 * k + r;
-        inv[k] = i < P;
-        oM[k] = tau * PP + (inv[k] ? P * P + i : 0);
-        oMp[k] = tau * RS + (inv[k] ? 2 * P * P + i : 0);
+        const bool iv = valid && i < P;
+        oM[k] = iv ? (g * PP + P * P + i) * 8 : TN_OOR;
+        oMst[k] = (iv && c == 0) ? oM[k] : TN_OOR;
+        oMp[k] = iv ? (g * RS + 2 * P * P + i) * 8 : TN_OOR;
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
             const int j = 4 * bb + c;
-            in[k][bb] = i < P && j < P;
-            const int e = in[k][bb] ? i * P + j : 0;
-            oS[k][bb] = tau * PP + e;
-            oG[k][bb] = tau * RS + e;
-            oP[k][bb] = tau * RS + P * P + e;
+            const bool in = iv && j < P;
+            oS[k][bb] = in ? (g * PP + i * P + j) * 8 : TN_OOR;
+            oG[k][bb] = in ? (g * RS + i * P + j) * 8 : TN_OOR;
+            oP[k][bb] = in ? (g * RS + P * P + i * P + j) * 8 : TN_OOR;
         }
     }
     const size_t tstride = (size_t)n_units * PP, wstride = (size_t)n_units * RS;
+    const double* const tw = tiles + (size_t)blockIdx.x * 4 * PP;
+    const double* const ww = ws + (size_t)blockIdx.x * 4 * RS;
+    const int tbytes = 4 * PP * 8, wbytes = 4 * RS * 8;
     // carry = filt[N] (solve.py:279-282)
     double Ms[NB][NB], ms[NB];
     {
-        const double* t = tiles + (size_t)a.N * tstride;
+        const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)a.N * tstride, tbytes);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            ms[k] = inv[k] ? t[oM[k]] : 0.0;
+            ms[k] = buf_ld(t, oM[k]);
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) Ms[k][bb] = in[k][bb] ? t[oS[k][bb]] : 0.0;
+            for (int bb = 0; bb < NB; ++bb) Ms[k][bb] = buf_ld(t, oS[k][bb]);
         }
     }
     struct Rec { double Gt[NB][NB], Sp[NB][NB], Sf[NB][NB], mp[NB], mf[NB]; };
     auto load = [&](int n, Rec& q) {
-        const double* t = tiles + (size_t)n * tstride;
-        const double* w = ws + (size_t)n * wstride;
+        const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)n * tstride, tbytes);
+        const __amdgpu_buffer_rsrc_t w = buf_window(ww + (size_t)n * wstride, wbytes);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            q.mp[k] = w[oMp[k]];
-            q.mf[k] = t[oM[k]];
+            q.mp[k] = buf_ld(w, oMp[k]);
+            q.mf[k] = buf_ld(t, oM[k]);
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) {
-                q.Gt[k][bb] = w[oG[k][bb]];
-                q.Sp[k][bb] = w[oP[k][bb]];
-                q.Sf[k][bb] = t[oS[k][bb]];
+                q.Gt[k][bb] = buf_ld(w, oG[k][bb]);
+                q.Sp[k][bb] = buf_ld(w, oP[k][bb]);
+                q.Sf[k][bb] = buf_ld(t, oS[k][bb]);
             }
         }
     };
     auto step = [&](int n, const Rec& q) {
-        double Dm[NB][NB], dm[NB], V1[NB][NB], Gt[NB][NB], Sf[NB][NB], mf[NB];
+        double Dm[NB][NB], dm[NB], V1[NB][NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            dm[k] = inv[k] ? ms[k] - q.mp[k] : 0.0;
-            mf[k] = inv[k] ? q.mf[k] : 0.0;
+            dm[k] = ms[k] - q.mp[k];
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) {
-                Dm[k][bb] = in[k][bb] ? Ms[k][bb] - q.Sp[k][bb] : 0.0;
-                Gt[k][bb] = in[k][bb] ? q.Gt[k][bb] : 0.0;
-                Sf[k][bb] = in[k][bb] ? q.Sf[k][bb] : 0.0;
-            }
+            for (int bb = 0; bb < NB; ++bb) Dm[k][bb] = Ms[k][bb] - q.Sp[k][bb];
         }
-        bmm_tn0<NB>(Dm, Gt, V1);                         // (G D)^T
-        bmm_tn<NB>(V1, Gt, Sf, Ms);                      // G D G^T + Sigma_f      (standard.py:215-216)
-        bmv_t<NB>(Gt, dm, mf, ms);                       // G (m_s - m-) + mu_f    (standard.py:213-214)
-        double* t = tiles + (size_t)n * tstride;
-        if (valid) {
+        bmm_tn0<NB>(Dm, q.Gt, V1);                       // (G D)^T
+        bmm_tn<NB>(V1, q.Gt, q.Sf, Ms);                  // G D G^T + Sigma_f      (standard.py:215-216)
+        bmv_t<NB>(q.Gt, dm, q.mf, ms);                   // G (m_s - m-) + mu_f    (standard.py:213-214)
+        const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)n * tstride, tbytes);
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                if (inv[k] && c == 0) t[oM[k]] = ms[k];
+        for (int k = 0; k < NB; ++k) {
+            buf_st(ms[k], t, oMst[k]);
 #pragma unroll
-                for (int bb = 0; bb < NB; ++bb)
-                    if (in[k][bb]) t[oS[k][bb]] = Ms[k][bb];
-            }
+            for (int bb = 0; bb < NB; ++bb) buf_st(Ms[k][bb], t, oS[k][bb]);
         }
     };
-    int n = a.N - 1;                                      // steps n = N-1 .. 1
-    while (n >= TN_CH) {                                  // a full chunk: steps n .. n - CH + 1 (all >= 1)
-        Rec q[TN_CH];
+    // steps n = N-1 .. 1 through a ring of TN_RING records: slot s is consumed and at once refilled with the record
+    // TN_RING steps further down, so TN_RING - 1 steps of loads are in flight all the time, also across loop iterations
+    // (indices below 1 are clamped: a harmless reload of step 1 that is never consumed)
+    int n = a.N - 1;
+    Rec q[TN_RING];
 #pragma unroll
-        for (int s = 0; s < TN_LA; ++s) load(n - s, q[s]);
+    for (int s = 0; s < TN_RING; ++s) load(n - s >= 1 ? n - s : 1, q[s]);
+    while (n >= TN_RING) {
 #pragma unroll
-        for (int s = 0; s < TN_CH; ++s) {
-            if (s + TN_LA < TN_CH) load(n - s - TN_LA, q[s + TN_LA]);
+        for (int s = 0; s < TN_RING; ++s) {
             step(n - s, q[s]);
+            const int nn = n - s - TN_RING;
+            load(nn >= 1 ? nn : 1, q[s]);
         }
-        n -= TN_CH;
+        n -= TN_RING;
     }
-    for (; n >= 1; --n) {
-        Rec q;
-        load(n, q);
-        step(n, q);
-    }
+#pragma unroll
+    for (int s = 0; s < TN_RING; ++s)
+        if (s < n) step(n - s, q[s]);                     // (uniform condition)
 }
 
 template <int NB>
@@ -222,77 +277,69 @@ __global__ void __launch_bounds__(64) bwd_sim_tilen_kernel(SolveArgs a, const do
     const int tau = valid ? tau_raw : n_units - 1;
     const int b = tau / D, blk = tau - b * D;
     int oG[NB][NB], oMp[NB], oW[NB];
-    bool in[NB][NB], inv[NB];
+    bool st[NB];
     size_t ox[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int i = 4 * k + r;
-        inv[k] = i < P;
-        oMp[k] = tau * RS + (inv[k] ? P * P + i : 0);
-        oW[k] = tau * RS + (inv[k] ? P * P + P + i : 0);
-        ox[k] = ((size_t)blk * P + (inv[k] ? i : 0)) * (size_t)a.B + b;          // x_state (N+1, d, p, B)
+        const bool iv = valid && i < P;
+        st[k] = iv && c == 0;
+        oMp[k] = iv ? (g * RS + P * P + i) * 8 : TN_OOR;
+        oW[k] = iv ? (g * RS + P * P + P + i) * 8 : TN_OOR;
+        ox[k] = ((size_t)blk * P + (i < P ? i : 0)) * (size_t)a.B + b;          // x_state (N+1, d, p, B)
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
             const int j = 4 * bb + c;
-            in[k][bb] = i < P && j < P;
-            oG[k][bb] = tau * RS + (in[k][bb] ? i * P + j : 0);
+            oG[k][bb] = (iv && j < P) ? (g * RS + i * P + j) * 8 : TN_OOR;
         }
     }
     const size_t wstride = (size_t)n_units * RS, xstride = (size_t)D * P * a.B;
+    const double* const ww = ws + (size_t)blockIdx.x * 4 * RS;
+    const int wbytes = 4 * RS * 8;
     struct Rec { double Gt[NB][NB], mp[NB], w[NB]; };
     auto load = [&](int n, Rec& q) {
-        const double* w = ws + (size_t)n * wstride;
+        const __amdgpu_buffer_rsrc_t w = buf_window(ww + (size_t)n * wstride, wbytes);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            q.mp[k] = w[oMp[k]];
-            q.w[k] = w[oW[k]];
+            q.mp[k] = buf_ld(w, oMp[k]);
+            q.w[k] = buf_ld(w, oW[k]);
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb) q.Gt[k][bb] = w[oG[k][bb]];
+            for (int bb = 0; bb < NB; ++bb) q.Gt[k][bb] = buf_ld(w, oG[k][bb]);
         }
     };
     double x[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) x[k] = 0.0;
     auto step = [&](int n, const Rec& q) {
-        double dx[NB], Gt[NB][NB], w[NB];
+        double dx[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            dx[k] = inv[k] ? x[k] - q.mp[k] : 0.0;
-            w[k] = inv[k] ? q.w[k] : 0.0;
-#pragma unroll
-            for (int bb = 0; bb < NB; ++bb) Gt[k][bb] = in[k][bb] ? q.Gt[k][bb] : 0.0;
-        }
-        bmv_t<NB>(Gt, dx, w, x);                         // x_n = G (x_{n+1} - mu-) + mu_f + L z   (standard.py:251-254, solve.py:179)
-        if (valid && c == 0) {
-            double* xo = a.x + (size_t)n * xstride;
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (inv[k]) xo[ox[k]] = x[k];
-        }
-    };
-    int n = a.N;                                          // steps n = N .. 1 (n = N: the terminal draw)
-    while (n >= TN_CH) {
-        Rec q[TN_CH];
-#pragma unroll
-        for (int s = 0; s < TN_LA; ++s) load(n - s, q[s]);
-#pragma unroll
-        for (int s = 0; s < TN_CH; ++s) {
-            if (s + TN_LA < TN_CH) load(n - s - TN_LA, q[s + TN_LA]);
-            step(n - s, q[s]);
-        }
-        n -= TN_CH;
-    }
-    for (; n >= 1; --n) {
-        Rec q;
-        load(n, q);
-        step(n, q);
-    }
-    // x[0] = ode_init exactly (solve.py:196-204): the mean of tile time 0
-    if (valid && c == 0) {
+        for (int k = 0; k < NB; ++k) dx[k] = x[k] - q.mp[k];
+        bmv_t<NB>(q.Gt, dx, q.w, x);                     // x_n = G (x_{n+1} - mu-) + mu_f + L z   (standard.py:251-254, solve.py:179)
+        double* xo = a.x + (size_t)n * xstride;
 #pragma unroll
         for (int k = 0; k < NB; ++k)
-            if (inv[k]) a.x[ox[k]] = tiles[(size_t)tau * PP + P * P + 4 * k + r];
+            if (st[k]) xo[ox[k]] = x[k];
+    };
+    int n = a.N;                                          // steps n = N .. 1 (n = N: the terminal draw), ring as above
+    Rec q[TN_RING];
+#pragma unroll
+    for (int s = 0; s < TN_RING; ++s) load(n - s >= 1 ? n - s : 1, q[s]);
+    while (n >= TN_RING) {
+#pragma unroll
+        for (int s = 0; s < TN_RING; ++s) {
+            step(n - s, q[s]);
+            const int nn = n - s - TN_RING;
+            load(nn >= 1 ? nn : 1, q[s]);
+        }
+        n -= TN_RING;
     }
+#pragma unroll
+    for (int s = 0; s < TN_RING; ++s)
+        if (s < n) step(n - s, q[s]);
+    // x[0] = ode_init exactly (solve.py:196-204): the mean of tile time 0
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (st[k]) a.x[ox[k]] = tiles[(size_t)tau * PP + P * P + 4 * k + r];
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------------------------

@@ -94,7 +94,6 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
         valid = blk_w < D;
         b = blockIdx.x; blk = valid ? blk_w : D - 1;
     }
-    const int tau = b * D + blk;
 
     // ---- per-lane constants, zero-padded to 4 NB ----
     double Qt[NB][NB], Rt[NB][NB], RtT[NB][NB], Wr[NB], Y0[NB];
@@ -131,26 +130,35 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
         for (int bb = 0; bb < NB; ++bb) S[k][bb] = 0.0;
     }
     // ---- output slots of this lane inside its unit's [Sigma | mu] record ----
+    // Stores go through a buffer window on this wave's units of the current time row (scalar base, per-lane byte offset):
+    // lanes without a slot (padding, idle units) carry an out-of-range offset and are dropped by the hardware, so the
+    // step has no exec-mask branches around its stores.
     const size_t tstride = (size_t)n_units * PP;
-    double* out = tiles + (size_t)tau * PP;
+    const size_t base_unit = NW == 1 ? (size_t)blockIdx.x * TPW : (size_t)blockIdx.x * D + (size_t)wave_in_wg * 4;
+    const char* row = (const char*)(tiles + base_unit * PP);
     int offS[NB][NB], offM[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int i = 4 * k + r;
-        offM[k] = (valid && c == 0 && i < P) ? P * P + i : -1;
+        offM[k] = (valid && c == 0 && i < P) ? (int)((g * PP + P * P + i) * sizeof(double)) : (int)0x80000000;
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
             const int j = 4 * bb + c;
-            offS[k][bb] = (valid && i < P && j < P) ? i * P + j : -1;
+            offS[k][bb] = (valid && i < P && j < P) ? (int)((g * PP + i * P + j) * sizeof(double)) : (int)0x80000000;
         }
     }
     auto store = [&]() {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, TPW * PP * 8, 0x00020000);
+        auto put = [&](double v, int off) {
+            u32x2 bits;
+            __builtin_memcpy(&bits, &v, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, off, 0, 0);
+        };
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            if (offM[k] >= 0) out[offM[k]] = m[k];
+            put(m[k], offM[k]);
 #pragma unroll
-            for (int bb = 0; bb < NB; ++bb)
-                if (offS[k][bb] >= 0) out[offS[k][bb]] = S[k][bb];
+            for (int bb = 0; bb < NB; ++bb) put(S[k][bb], offS[k][bb]);
         }
     };
     store();
@@ -238,7 +246,7 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) S[k][bb] = fma(-K, WS[bb], Sp[k][bb]);
         }
-        out += tstride;
+        row += tstride * sizeof(double);
         store();
     }
 }

@@ -79,7 +79,7 @@ def c5(args):
     X0 = np.zeros((B, n_vars, n_deriv)); X0[..., 0] = x0v; X0[..., 1] = x0v @ A.T
     X0 = X0.reshape(B, 1, -1)
     plan = ra.SolvePlan(ra.ode.linear_dense(n_vars, n_deriv), W, X0, 0.0, N / 2000.0, N,
-                        ra.interrogate.interrogate_kramer, prior, A=A)
+                        getattr(ra.interrogate, "interrogate_" + args.c5_itg), prior, A=A)
     dev = plan.dev
     dev.profile_enable(True)
     t0 = time.perf_counter(); plan.mv(None); dev.sync(); wall = time.perf_counter() - t0
@@ -97,7 +97,7 @@ def c5(args):
         names = ["predict+T+diff", "LU panel", "LU swaps", "LU trsm", "LU gemm", "back trsm", "back gemm", "mean", "G D", "GDG^T"]
         cyc = ws[0, -2:-12:-1] / (N - 1)            # library built with -DRK_DENSE_STAMPS (solve_dense.hip)
         print("bwd phase cycles per step (wg 0):", {k: int(v) for k, v in zip(names, cyc)}, "total", int(cyc.sum()), file=sys.stderr)
-    return {"config": f"C5 dense p=160 m=32 N={N} B={B} solve_mv+kramer", "ms": ms, "kernels_ms": prof,
+    return {"config": f"C5 dense p=160 m=32 N={N} B={B} solve_mv+{args.c5_itg}", "ms": ms, "kernels_ms": prof,
             "traj_steps_per_s": B * N / ms * 1e3, "tflops": F * B * N / (ms * 1e-3) / 1e12,
             "frac_fp64_peak_78.6TF": F * B * N / (ms * 1e-3) / 78.6e12, "wall_s": wall}
 
@@ -106,7 +106,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["c3", "c4", "c5"])
     ap.add_argument("--c5-batch", type=int, default=256)
-    ap.add_argument("--c5-steps", type=int, default=50)
+    ap.add_argument("--c5-steps", type=int, default=2000)      # BASELINE config 5: N = 2000
+    ap.add_argument("--c5-itg", default="kramer", choices=["kramer", "rodeo", "schober"])
     args = ap.parse_args()
     for w in args.which:
         print(json.dumps({"c3": c3, "c4": c4, "c5": c5}[w](args)), flush=True)
