@@ -36,6 +36,7 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
     if (kind == 2) snprintf(buf, sizeof buf, "rk::interrogate_kernel<rk::UserRhsT, %d, %d>", P, itg);
     else if (kind == 3) snprintf(buf, sizeof buf, "rk::fwd_tile3_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 3
     else if (kind == 4) snprintf(buf, sizeof buf, "rk::fwd_tile4_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 4
+    else if (kind == 6) snprintf(buf, sizeof buf, "rk::fwd_sqrt_kernel<rk::UserRhsT, %d, %d>", P, itg);   // square-root filter
     else if (kind == 5) snprintf(buf, sizeof buf, "rk::fwd_tilen_kernel<rk::UserRhsT, %d, %d>", itg, P); // blocked tiles, P here = NB
     else snprintf(buf, sizeof buf, "rk::fwd_kernel<rk::UserRhsT, %d, %d, %s>", P, itg, kind == 1 ? "true" : "false");
     return buf;
@@ -45,7 +46,7 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
 static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<char>& code, std::string& lowered) {
     const std::string src = std::string("#include \"solve_small_kernels.hpp\"\n#include \"dual.hpp\"\n"
                                         "#include \"solve_tile3_kernels.hpp\"\n#include \"solve_tile4_kernels.hpp\"\n"
-                                        "#include \"solve_tilen_kernels.hpp\"\nnamespace rk {\n") +
+                                        "#include \"solve_tilen_kernels.hpp\"\n#include \"solve_sqrt_kernels.hpp\"\nnamespace rk {\n") +
                             u.source + "\nusing UserRhsT = " + u.type_name + ";\n}  // namespace rk\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rk_user_rhs.hip", kJitNumHeaders, kJitHeaderSources, kJitHeaderNames) !=
@@ -153,6 +154,25 @@ int user_forward_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, do
 
 bool is_user_rhs(int rhs_id) { return rhs_id >= RK_RHS_USER_BASE; }
 
+int user_forward_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        const int idx = c->rhs_id - RK_RHS_USER_BASE;
+        RK_REQUIRE(idx >= 0 && idx < (int)g_rhs.size(), RK_ERR_INVALID, "unknown user rhs_id %d", c->rhs_id);
+        RK_REQUIRE(c->n_block == g_rhs[idx].n_block && c->n_bmeas == 1, RK_ERR_UNSUPPORTED,
+                   "user rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, g_rhs[idx].n_block, c->n_block, c->n_bmeas);
+    }
+    hipFunction_t fn;
+    int rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, 6, &fn);
+    if (rc) return rc;
+    SolveArgs args = a;
+    void* params[] = {&args};
+    LaunchTimer t(h, "fwd_sqrt_kernel<user>");
+    RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B, 64), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));
+    t.stop();
+    return RK_OK;
+}
+
 int user_rhs_check(const rk_solve_cfg* c) {
     std::lock_guard<std::mutex> lk(g_mu);
     const int idx = c->rhs_id - RK_RHS_USER_BASE;
@@ -161,8 +181,6 @@ int user_rhs_check(const rk_solve_cfg* c) {
                "user rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, g_rhs[idx].n_block, c->n_block, c->n_bmeas);
     RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 5, RK_ERR_UNSUPPORTED, "small-block path supports n_bstate in [2, 5], got %d",
                c->n_bstate);
-    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED,
-               "user right-hand sides are available with kalman_type=standard only");
     return RK_OK;
 }
 

@@ -578,11 +578,7 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     h->event_used = 0;
     SolveArgs a;
     make_args(c, in, out, a);
-    if (c->kalman_type == RK_KALMAN_SQRT) {
-        RK_REQUIRE(!is_user_rhs(c->rhs_id), RK_ERR_UNSUPPORTED,
-                   "user right-hand sides are available with kalman_type=standard only");
-        return sqrt_solve(h, c, a, mode);
-    }
+    if (c->kalman_type == RK_KALMAN_SQRT) return sqrt_solve(h, c, a, mode);
     if (tile4) return tile4_solve(h, c, a, out->var_state, mode);
     if (tile3) return tile3_solve(h, c, a, out->var_state, mode);
     if (tilen) return tilen_solve(h, c, a, out->var_state, (double*)out->workspace, out->workspace_bytes, mode);

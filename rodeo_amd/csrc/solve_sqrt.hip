@@ -14,112 +14,9 @@
 #include "rhs.hpp"
 #include "solve_args.hpp"
 #include "sqrt_small.hpp"
+#include "solve_sqrt_kernels.hpp"
 
 namespace rk {
-
-template <class RHS, int P, int ITG>
-__global__ void __launch_bounds__(64) fwd_sqrt_kernel(SolveArgs a) {
-    constexpr int D = RHS::D;
-    constexpr int KV = ITG == RK_INTERROGATE_CHKREBTII ? P : 1;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
-    const size_t B = (size_t)a.B;
-    double W[D][P], th[RHS::NTHETA], mu[D][P], L[D][P][P];
-#pragma unroll
-    for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
-#pragma unroll
-    for (int blk = 0; blk < D; ++blk)
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const size_t em = (size_t)blk * P + i;
-            W[blk][i] = ld(a.W, em, a.W_b, a.B, b);
-            mu[blk][i] = ld(a.x0, em, a.x0_b, a.B, b);
-            a.mean[em * B + b] = mu[blk][i];
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                L[blk][i][j] = 0.0;
-                a.var[(em * P + j) * B + b] = 0.0;
-            }
-        }
-    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
-    const size_t mstride = (size_t)D * P * B, vstride = (size_t)D * P * P * B;
-    for (int n = 0; n < a.N; ++n) {
-        double mup[D][P], Lp[D][P][P];
-#pragma unroll
-        for (int blk = 0; blk < D; ++blk) {
-            double Q[P][P], LR[P][P];
-            load_block_consts<P>(a, blk, b, Q, LR);
-            sqrt_predict<P>(Q, LR, mu[blk], L[blk], mup[blk], Lp[blk]);                  // square_root.py:56-57
-        }
-        const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;  // solve.py:74
-        // ---- interrogation (interrogate.py) with the factor standing where the reference puts it ----
-        double f[D], wgt[D][P], am[D], vm[D][KV];
-        if constexpr (ITG == RK_INTERROGATE_KRAMER) {
-            double J[D][P];
-            RHS::template fjac<P>(mup, t, th, f, J);
-#pragma unroll
-            for (int blk = 0; blk < D; ++blk) {
-                am[blk] = -f[blk] + dot<P>(J[blk], mup[blk]);
-                vm[blk][0] = 0.0;
-#pragma unroll
-                for (int j = 0; j < P; ++j) wgt[blk][j] = -J[blk][j];
-            }
-        } else {
-            double WL[D][P];
-#pragma unroll
-            for (int blk = 0; blk < D; ++blk)
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    double s = W[blk][0] * Lp[blk][0][j];
-#pragma unroll
-                    for (int i = 1; i < P; ++i) s = fma(W[blk][i], Lp[blk][i][j], s);
-                    WL[blk][j] = s;
-                }
-            if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
-                // interrogate.py:36-42: var_meas = W L- (1 x p) ; x = mu- + (W L-) . z  (one scalar added to every entry)
-                double xs[D][P];
-#pragma unroll
-                for (int blk = 0; blk < D; ++blk) {
-                    double z[P];
-                    normals<P>(a.seed, traj, (uint32_t)n, (uint32_t)blk, PURPOSE_INTERROGATE, z);
-#pragma unroll
-                    for (int j = 0; j < P; ++j) z[j] = Lp[blk][j][j] < 0.0 ? -z[j] : z[j];   // sign-normalised factor
-                    const double shift = dot<P>(WL[blk], z);
-#pragma unroll
-                    for (int j = 0; j < P; ++j) { xs[blk][j] = mup[blk][j] + shift; vm[blk][j] = WL[blk][j]; }
-                }
-                RHS::template f<P>(xs, t, th, f);
-            } else {
-                RHS::template f<P>(mup, t, th, f);
-#pragma unroll
-                for (int blk = 0; blk < D; ++blk)
-                    vm[blk][0] = ITG == RK_INTERROGATE_RODEO ? dot<P>(WL[blk], W[blk]) : 0.0;   // interrogate.py:110-113 / :60
-            }
-#pragma unroll
-            for (int blk = 0; blk < D; ++blk) {
-                am[blk] = -f[blk];
-#pragma unroll
-                for (int j = 0; j < P; ++j) wgt[blk][j] = 0.0;
-            }
-        }
-        double* mo = a.mean + (size_t)(n + 1) * mstride + b;
-        double* vo = a.var + (size_t)(n + 1) * vstride + b;
-#pragma unroll
-        for (int blk = 0; blk < D; ++blk) {
-            double Wm[P];
-#pragma unroll
-            for (int j = 0; j < P; ++j) Wm[j] = W[blk][j] + wgt[blk][j];                   // solve.py:79
-            sqrt_update_m1<P, KV>(Wm, am[blk], vm[blk], mup[blk], Lp[blk], mu[blk], L[blk]);
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const size_t em = (size_t)blk * P + i;
-                mo[em * B] = mu[blk][i];
-#pragma unroll
-                for (int j = 0; j < P; ++j) vo[(em * P + j) * B] = L[blk][i][j];
-            }
-        }
-    }
-}
 
 template <int P>
 __device__ __forceinline__ void load_state(const SolveArgs& a, int n, int blk, int b, double (&mf)[P],
@@ -236,14 +133,22 @@ static int launch_fwd_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& 
         case 2: return launch_fwd_sqrt_p<RHS, 2>(h, a, c->interrogate);
         case 3: return launch_fwd_sqrt_p<RHS, 3>(h, a, c->interrogate);
         case 4: return launch_fwd_sqrt_p<RHS, 4>(h, a, c->interrogate);
+        case 5: return launch_fwd_sqrt_p<RHS, 5>(h, a, c->interrogate);
+        case 6: return launch_fwd_sqrt_p<RHS, 6>(h, a, c->interrogate);
     }
-    set_error("square-root solver supports n_bstate in [2, 4], got %d", c->n_bstate);
+    set_error("square-root solver supports n_bstate in [2, 6], got %d", c->n_bstate);
     return RK_ERR_UNSUPPORTED;
 }
 
+bool is_user_rhs(int rhs_id);
+int user_forward_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a);
+
 int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode) {
+    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6, RK_ERR_UNSUPPORTED, "square-root solver supports n_bstate in [2, 6], got %d",
+               c->n_bstate);
     int rc;
-    switch (c->rhs_id) {
+    if (is_user_rhs(c->rhs_id)) rc = user_forward_sqrt(h, c, a);      // hiprtc build of fwd_sqrt_kernel (rhs_jit.hip)
+    else switch (c->rhs_id) {
         case RK_RHS_FITZHUGH_NAGUMO: rc = launch_fwd_sqrt<FitzHughNagumo>(h, c, a); break;
         case RK_RHS_LORENZ63: rc = launch_fwd_sqrt<Lorenz63>(h, c, a); break;
         case RK_RHS_HIGHER_ORDER: rc = launch_fwd_sqrt<HigherOrder>(h, c, a); break;
@@ -257,7 +162,7 @@ int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode)
         if (mode == RK_MODE_SIM) hipLaunchKernelGGL((bwd_sqrt_kernel<P_, true>), grid, block, 0, h->stream, a);  \
         else hipLaunchKernelGGL((bwd_sqrt_kernel<P_, false>), grid, block, 0, h->stream, a);             \
         break;
-    switch (c->n_bstate) { RK_SQ(2) RK_SQ(3) RK_SQ(4) }
+    switch (c->n_bstate) { RK_SQ(2) RK_SQ(3) RK_SQ(4) RK_SQ(5) RK_SQ(6) }
 #undef RK_SQ
     t.stop();
     RK_HIP(hipGetLastError());
