@@ -198,13 +198,14 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
  * cfg / in, fenrir.py:304-313): log p(y_{0:M} | Z_{1:N}) per trajectory from the filter's output in `out` -- either
  * the RK_LAYOUT_TILE3 tiles (no flags; predicted moments are re-evaluated on the fly) when rk_solve_layout reports that
  * layout for RK_MODE_FILTER, or the batch-minor filtered and predicted moments of a call with
- * RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR.  Observations are scalar per
- * block (n_bobs = 1): obs (n_obs, d), obs_weight (n_obs, d, p), obs_var (n_obs, d) row-major on device, shared by all
- * trajectories; obs_ind (n_obs) = searchsorted(sim_times, obs_times), ascending.  logdens (B) is overwritten.
- * The log-density follows src/rodeo/utils.py:60-78 (a forecast variance with |w| <= 1e-8 contributes nothing).      */
+ * RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR (required when n_bobs > 1).  Observations (fenrir.py:106-122), n_bobs = 1..3
+ * per block: obs (n_obs, d, n_bobs), obs_weight (n_obs, d, n_bobs, p), obs_var (n_obs, d, n_bobs, n_bobs) row-major on
+ * device, shared by all trajectories; obs_ind (n_obs) = searchsorted(sim_times, obs_times), ascending.  logdens (B) is
+ * overwritten.  The log-density follows src/rodeo/utils.py:60-78 (eigendecomposition of the forecast variance;
+ * eigenvalues with |w| <= 1e-8 contribute nothing).                                                                 */
 int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
-                       int32_t n_obs, double* logdens);
+                       int32_t n_obs, int32_t n_bobs, double* logdens);
 
 /* Fenrir's data-adaptive solver (src/rodeo/inference/fenrir.py:333-457 `_smooth_mv`, `solve_mv`): mean and variance of
  * p(X_{0:N} | Z_{1:N}, Y_{0:M}).  Input as for rk_fenrir_backward with RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR; the
@@ -213,7 +214,7 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* 
 int rk_fenrir_workspace_bytes(const rk_solve_cfg* cfg, size_t* bytes);
 int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
-                       int32_t n_obs, void* workspace);
+                       int32_t n_obs, int32_t n_bobs, void* workspace);
 
 /* ---- per-step operator boundary -------------------------------------------------------------------------
  * Batched versions of the nine functions of src/rodeo/kalmantv/standard.py (kalman_type = RK_KALMAN_STANDARD)

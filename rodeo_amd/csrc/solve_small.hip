@@ -159,7 +159,48 @@ __global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile,
 // With STORE (fenrir.py:236-258, for fenrir's solve_mv) the backward filter's predicted and updated moments of every
 // time and the Markov weights A_n are kept in `states`: per (time n, block) an item of 3 P^2 + 2 P doubles
 // [m_pred (P), S_pred (P^2), m_filt (P), S_filt (P^2), A (P^2)], batch-minor.
-template <int P, bool STORE>
+// Symmetric M x M eigendecomposition by cyclic Jacobi rotations (M <= 3: eight sweeps are far past convergence):
+// A is destroyed, w <- eigenvalues, V <- eigenvectors in its columns.  For the log-density rule of utils.py:60-78
+// (jnp.linalg.eigh, eigenvalues with |w| <= 1e-8 dropped); the value does not depend on the order or signs returned.
+template <int M>
+__device__ __forceinline__ void sym_eig_jacobi(double (&A)[M][M], double (&w)[M], double (&V)[M][M]) {
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+        for (int p_ = 0; p_ < M - 1; ++p_)
+#pragma unroll
+            for (int q = p_ + 1; q < M; ++q) {
+                const double apq = A[p_][q];
+                const bool go = apq != 0.0;
+                const double theta = go ? (A[q][q] - A[p_][p_]) / (2.0 * apq) : 0.0;
+                const double t = go ? (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)) : 0.0;
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < M; ++k) {                    // A <- A J
+                    const double akp = A[k][p_], akq = A[k][q];
+                    A[k][p_] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < M; ++k) {                    // A <- J^T A ; V <- V J
+                    const double apk = A[p_][k], aqk = A[q][k];
+                    A[p_][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                    const double vkp = V[k][p_], vkq = V[k][q];
+                    V[k][p_] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) w[i] = A[i][i];
+}
+
+// MO = n_bobs (observations per block, fenrir.py:106-122): obs (n_obs, d, MO), obs_w (n_obs, d, MO, P), obs_v (n_obs, d, MO, MO)
+template <int P, bool STORE, int MO>
 __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const double* __restrict__ obs,
                                                         const double* __restrict__ obs_w, const double* __restrict__ obs_v,
                                                         const int32_t* __restrict__ obs_ind, int n_obs,
@@ -177,30 +218,99 @@ __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const doubl
     int i = n_obs - 1;
     // forecast (standard.py:333-335) + log-density + update (standard.py:93-102) with observation i
     auto observe = [&](double (&m)[P], double (&S)[P][P]) {
-        double D[P], SD[P];
+        if constexpr (MO == 1) {
+            double D[P], SD[P];
 #pragma unroll
-        for (int k = 0; k < P; ++k) D[k] = obs_w[((size_t)i * a.D + blk) * P + k];
-        const double y = obs[(size_t)i * a.D + blk], Om = obs_v[(size_t)i * a.D + blk];
-        const double mean_fore = dot<P>(D, m);
+            for (int k = 0; k < P; ++k) D[k] = obs_w[((size_t)i * a.D + blk) * P + k];
+            const double y = obs[(size_t)i * a.D + blk], Om = obs_v[(size_t)i * a.D + blk];
+            const double mean_fore = dot<P>(D, m);
 #pragma unroll
-        for (int r = 0; r < P; ++r) SD[r] = dot<P>(S[r], D);                // Sigma D^T
-        double DS[P];
+            for (int r = 0; r < P; ++r) SD[r] = dot<P>(S[r], D);                // Sigma D^T
+            double DS[P];
 #pragma unroll
-        for (int c = 0; c < P; ++c) {
-            double t = D[0] * S[0][c];
+            for (int c = 0; c < P; ++c) {
+                double t = D[0] * S[0][c];
 #pragma unroll
-            for (int k = 1; k < P; ++k) t = fma(D[k], S[k][c], t);
-            DS[c] = t;                                                      // D Sigma
-        }
-        const double w = dot<P>(DS, D) + Om;                                // var_fore
-        const double z = y - mean_fore;
-        if (fabs(w) > 1e-8) acc += -0.5 * (z * z / w + log(w)) - 0.5 * LOG_2PI;
+                for (int k = 1; k < P; ++k) t = fma(D[k], S[k][c], t);
+                DS[c] = t;                                                      // D Sigma
+            }
+            const double w = dot<P>(DS, D) + Om;                                // var_fore
+            const double z = y - mean_fore;
+            if (fabs(w) > 1e-8) acc += -0.5 * (z * z / w + log(w)) - 0.5 * LOG_2PI;
 #pragma unroll
-        for (int r = 0; r < P; ++r) {
-            const double K = SD[r] / w;                                     // solve_var with a 1 x 1 system
-            m[r] = fma(K, z, m[r]);
+            for (int r = 0; r < P; ++r) {
+                const double K = SD[r] / w;                                     // solve_var with a 1 x 1 system
+                m[r] = fma(K, z, m[r]);
 #pragma unroll
-            for (int c = 0; c < P; ++c) S[r][c] = fma(-K, DS[c], S[r][c]);
+                for (int c = 0; c < P; ++c) S[r][c] = fma(-K, DS[c], S[r][c]);
+            }
+        } else {
+            // vector observation of this block: y (MO), D (MO x P), Omega (MO x MO)
+            double D[MO][P], y[MO], Wf[MO][MO], DS[MO][P], X[MO][P], z[MO];
+            const size_t ib = (size_t)i * a.D + blk;
+#pragma unroll
+            for (int j = 0; j < MO; ++j) {
+                y[j] = obs[ib * MO + j];
+#pragma unroll
+                for (int k = 0; k < P; ++k) D[j][k] = obs_w[(ib * MO + j) * P + k];
+            }
+#pragma unroll
+            for (int j = 0; j < MO; ++j) {
+                z[j] = y[j] - dot<P>(D[j], m);                                   // x_meas - (D mu + 0)
+#pragma unroll
+                for (int c = 0; c < P; ++c) {
+                    double t = D[j][0] * S[0][c];
+#pragma unroll
+                    for (int k = 1; k < P; ++k) t = fma(D[j][k], S[k][c], t);
+                    DS[j][c] = t;                                               // D Sigma  (var_meas_state_pred)
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MO; ++j)
+#pragma unroll
+                for (int l2 = 0; l2 < MO; ++l2) Wf[j][l2] = dot<P>(DS[j], D[l2]) + obs_v[(ib * MO + j) * MO + l2];   // var_fore
+            {   // log N(y; D mu, var_fore) by eigendecomposition (utils.py:60-78)
+                double Aw[MO][MO], w[MO], V[MO][MO];
+#pragma unroll
+                for (int j = 0; j < MO; ++j)
+#pragma unroll
+                    for (int l2 = 0; l2 < MO; ++l2) Aw[j][l2] = 0.5 * (Wf[j][l2] + Wf[l2][j]);
+                sym_eig_jacobi<MO>(Aw, w, V);
+#pragma unroll
+                for (int k = 0; k < MO; ++k) {
+                    double zk = 0.0;
+#pragma unroll
+                    for (int j = 0; j < MO; ++j) zk = fma(V[j][k], z[j], zk);
+                    if (fabs(w[k]) > 1e-8) acc += -0.5 * (zk * zk / w[k] + log(w[k])) - 0.5 * LOG_2PI;
+                }
+            }
+            // K^T = solve(var_fore, (Sigma D^T)^T) by LU with partial pivoting (utils.py:119)
+#pragma unroll
+            for (int j = 0; j < MO; ++j)
+#pragma unroll
+                for (int r = 0; r < P; ++r) X[j][r] = dot<P>(S[r], D[j]);        // (Sigma D^T)^T, row j
+            lu_solve<MO, P>(Wf, X);
+            double dm[P], dS[P][P];
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                double t = X[0][r] * z[0];
+#pragma unroll
+                for (int j = 1; j < MO; ++j) t = fma(X[j][r], z[j], t);
+                dm[r] = t;
+#pragma unroll
+                for (int c = 0; c < P; ++c) {
+                    double u = X[0][r] * DS[0][c];
+#pragma unroll
+                    for (int j = 1; j < MO; ++j) u = fma(X[j][r], DS[j][c], u);
+                    dS[r][c] = u;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                m[r] = m[r] + dm[r];                                            // mu + K (y - D mu)
+#pragma unroll
+                for (int c = 0; c < P; ++c) S[r][c] = S[r][c] - dS[r][c];       // Sigma - K (D Sigma)
+            }
         }
         --i;
     };
@@ -646,11 +756,12 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
 
 int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
-                       int32_t n_obs, double* logdens) {
+                       int32_t n_obs, int32_t n_bobs, double* logdens) {
     RK_REQUIRE(h && c && in && out && obs && obs_weight && obs_var && obs_ind && logdens, RK_ERR_INVALID,
                "rk_fenrir_backward: null argument");
     RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_backward: kalman_type must be standard");
-    if (!(c->flags & (RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)) && tile3_supported(c, RK_MODE_FILTER)) {
+    RK_REQUIRE(n_bobs >= 1 && n_bobs <= 3, RK_ERR_UNSUPPORTED, "rk_fenrir_backward: n_bobs in 1..3, got %d", n_bobs);
+    if (n_bobs == 1 && !(c->flags & (RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)) && tile3_supported(c, RK_MODE_FILTER)) {
         // the filter ran on the MFMA-tile path: out->var_state holds the RK_LAYOUT_TILE3 tiles, predicted moments are
         // re-evaluated from the filtered ones (solve_tile3.hip, fenrir_bwd_tile3_kernel)
         RK_REQUIRE(out->var_state && n_obs >= 0, RK_ERR_INVALID, "rk_fenrir_backward: out->var_state (tiles) is null");
@@ -665,7 +776,7 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
                "rk_fenrir_backward needs the batch-minor filtered AND predicted moments of rk_solve_filter "
                "(RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR), or a configuration of the tile path (n_bstate = 3) without them");
     RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6 && n_obs >= 0, RK_ERR_UNSUPPORTED,
-               "rk_fenrir_backward: n_bstate in 2..6, scalar observations per block");
+               "rk_fenrir_backward: n_bstate in 2..6");
     SolveArgs a;
     int rc = make_args(c, in, out, a);
     if (rc) return rc;
@@ -673,12 +784,22 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
     RK_HIP(hipMemsetAsync(logdens, 0, sizeof(double) * (size_t)c->n_traj, h->stream));
     const dim3 grid(div_up(a.B * a.D, 64)), block(64);
     LaunchTimer t(h, "fenrir_bwd_kernel");
-    switch (c->n_bstate) {
-        case 2: hipLaunchKernelGGL((fenrir_bwd_kernel<2, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
-        case 3: hipLaunchKernelGGL((fenrir_bwd_kernel<3, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
-        case 4: hipLaunchKernelGGL((fenrir_bwd_kernel<4, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
-        case 5: hipLaunchKernelGGL((fenrir_bwd_kernel<5, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
-        default: hipLaunchKernelGGL((fenrir_bwd_kernel<6, false>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr); break;
+    {
+            if (c->n_bstate == 2 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<2, false, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 2 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<2, false, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 2 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<2, false, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 3 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<3, false, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 3 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<3, false, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 3 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<3, false, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 4 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<4, false, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 4 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<4, false, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 4 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<4, false, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 5 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<5, false, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 5 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<5, false, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 5 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<5, false, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 6 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<6, false, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 6 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<6, false, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
+            if (c->n_bstate == 6 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<6, false, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr);
     }
     t.stop();
     RK_HIP(hipGetLastError());
@@ -694,7 +815,7 @@ int rk_fenrir_workspace_bytes(const rk_solve_cfg* c, size_t* bytes) {
 
 int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
-                       int32_t n_obs, void* workspace) {
+                       int32_t n_obs, int32_t n_bobs, void* workspace) {
     RK_REQUIRE(h && c && in && out && obs && obs_weight && obs_var && obs_ind && workspace, RK_ERR_INVALID,
                "rk_fenrir_solve_mv: null argument");
     RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_solve_mv: kalman_type must be standard");
@@ -702,8 +823,8 @@ int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
                out->mean_pred && out->var_pred, RK_ERR_INVALID,
                "rk_fenrir_solve_mv needs the batch-minor filtered AND predicted moments of rk_solve_filter "
                "(RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)");
-    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6 && n_obs >= 0, RK_ERR_UNSUPPORTED,
-               "rk_fenrir_solve_mv: n_bstate in 2..6, scalar observations per block");
+    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6 && n_obs >= 0 && n_bobs >= 1 && n_bobs <= 3, RK_ERR_UNSUPPORTED,
+               "rk_fenrir_solve_mv: n_bstate in 2..6, n_bobs in 1..3");
     SolveArgs a;
     int rc = make_args(c, in, out, a);
     if (rc) return rc;
@@ -712,12 +833,22 @@ int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
     double* st = (double*)workspace;
     {
         LaunchTimer t(h, "fenrir_bwd_kernel");
-        switch (c->n_bstate) {
-            case 2: hipLaunchKernelGGL((fenrir_bwd_kernel<2, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
-            case 3: hipLaunchKernelGGL((fenrir_bwd_kernel<3, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
-            case 4: hipLaunchKernelGGL((fenrir_bwd_kernel<4, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
-            case 5: hipLaunchKernelGGL((fenrir_bwd_kernel<5, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
-            default: hipLaunchKernelGGL((fenrir_bwd_kernel<6, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st); break;
+        {
+            if (c->n_bstate == 2 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<2, true, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 2 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<2, true, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 2 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<2, true, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 3 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<3, true, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 3 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<3, true, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 3 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<3, true, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 4 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<4, true, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 4 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<4, true, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 4 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<4, true, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 5 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<5, true, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 5 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<5, true, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 5 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<5, true, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 6 && n_bobs == 1) hipLaunchKernelGGL((fenrir_bwd_kernel<6, true, 1>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 6 && n_bobs == 2) hipLaunchKernelGGL((fenrir_bwd_kernel<6, true, 2>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
+            if (c->n_bstate == 6 && n_bobs == 3) hipLaunchKernelGGL((fenrir_bwd_kernel<6, true, 3>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st);
         }
         t.stop();
     }

@@ -7,8 +7,12 @@ the MFMA-tile kernels at n_bstate = 3, else lane-per-trajectory with ``RK_FLAG_S
 only B doubles come back.
 
 Same signature as the reference.  Extension: a leading batch axis on ``ode_init`` / ``prior_pars`` / ``**params``
-(observations are shared) returns an array (B,).  Restrictions of this build: ``kalman_type="standard"``, scalar
-observations per block (``obs_weight`` (n_obs, n_block, 1, n_bstate), ``obs_var`` (n_obs, n_block, 1, 1)).
+(observations are shared) returns an array (B,).  Observations per block: n_bobs = 1 .. 3 (``obs_data`` (n_obs, n_block,
+n_bobs), ``obs_weight`` (n_obs, n_block, n_bobs, n_bstate), ``obs_var`` (n_obs, n_block, n_bobs, n_bobs), fenrir.py:106-122);
+vector observations run on the lane-per-trajectory kernels (LU update, eigendecomposition log-density of utils.py:60-78).
+Restriction of this build: ``kalman_type="standard"`` -- the reference's square-root variant hands the Cholesky FACTOR of
+the forecast variance to ``multivariate_normal_logpdf`` as if it were the covariance (fenrir.py:63-70 with
+square_root.py's forecast), so its value is not a log-likelihood; it is not reproduced.
 """
 import ctypes as C
 import numpy as np
@@ -23,18 +27,14 @@ def fenrir(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogat
         raise NotImplementedError                                   # fenrir.py:293-298
     if kalman_type != "standard":
         raise NotImplementedError("fenrir on the device: kalman_type='standard' only in this build")
-    obs = np.asarray(obs_data, dtype=np.float64)
-    D = np.asarray(obs_weight, dtype=np.float64)
-    Om = np.asarray(obs_var, dtype=np.float64)
-    if D.ndim != 4 or D.shape[2] != 1 or Om.shape != D.shape[:2] + (1, 1) or obs.shape != D.shape[:2] + (1,):
-        raise ValueError("fenrir: obs_data (n_obs, n_block, 1), obs_weight (n_obs, n_block, 1, n_bstate), obs_var "
-                         "(n_obs, n_block, 1, 1) -- scalar observations per block in this build")
+    obs, D, Om, n_bobs = _check_obs(obs_data, obs_weight, obs_var)
     ind = obs_index(t_min, t_max, n_steps, obs_times)             # fenrir.py:118-120
     if np.any(np.diff(ind) < 0):
         raise ValueError("obs_times must be ascending")
-    plan = _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params)
-    if D.shape[1:] != (plan.d, 1, plan.p):
-        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, 1, {plan.p})")
+    plan = _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params,
+                     tiles_ok=n_bobs == 1)
+    if D.shape[1:] != (plan.d, n_bobs, plan.p):
+        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, n_bobs, {plan.p})")
     plan.filter(key)
     dev = plan.dev
     # observations live on the plan and are uploaded again only when they change (a sampler calls this once per step)
@@ -42,17 +42,33 @@ def fenrir(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogat
     sig = (obs.tobytes(), D.tobytes(), Om.tobytes(), ind.tobytes())
     if cache.get("sig") != sig:
         cache["sig"] = sig
-        cache["dev"] = tuple(dev.to_device(np.ascontiguousarray(a)) for a in
-                             (obs[:, :, 0], D[:, :, 0, :], Om[:, :, 0, 0], ind.astype(np.int32)))
+        cache["dev"] = tuple(dev.to_device(np.ascontiguousarray(a)) for a in (obs, D, Om, ind.astype(np.int32)))
     d_obs, d_w, d_v, d_ind = cache["dev"]
     out = dev.empty((plan.B,))
     _lib.check(dev.lib.rk_fenrir_backward(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(plan._out), d_obs.ptr,
-                                          d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), out.ptr))
+                                          d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), n_bobs, out.ptr))
     ll = out.to_host()
     return ll if plan.batched else float(ll[0])
 
 
-def _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params):
+def _check_obs(obs_data, obs_weight, obs_var):
+    """(obs (n_obs, d, n_bobs), D (n_obs, d, n_bobs, p), Omega (n_obs, d, n_bobs, n_bobs), n_bobs) as contiguous float64."""
+    obs = np.ascontiguousarray(obs_data, dtype=np.float64)
+    D = np.ascontiguousarray(obs_weight, dtype=np.float64)
+    Om = np.ascontiguousarray(obs_var, dtype=np.float64)
+    if D.ndim != 4:
+        raise ValueError("fenrir: obs_weight must have shape (n_obs, n_block, n_bobs, n_bstate)")
+    n_bobs = D.shape[2]
+    if not 1 <= n_bobs <= 3:
+        raise NotImplementedError("fenrir on the device: n_bobs (observations per block) in 1..3")
+    if Om.shape != D.shape[:2] + (n_bobs, n_bobs) or obs.shape != D.shape[:2] + (n_bobs,):
+        raise ValueError("fenrir: obs_data (n_obs, n_block, n_bobs), obs_weight (n_obs, n_block, n_bobs, n_bstate), obs_var "
+                         "(n_obs, n_block, n_bobs, n_bobs)")
+    return obs, D, Om, n_bobs
+
+
+def _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params,
+              tiles_ok=True):
     """A (cached, solve.cached_plan) plan on the MFMA-tile forward kernels when the configuration has them (n_bstate = 3:
     the backward pass then re-evaluates the predicted moments from the filtered tiles), else on the lane-per-trajectory
     kernels with stored predictions."""
@@ -60,7 +76,7 @@ def _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate,
     plan = cached_plan(*args, **params)
     lay = C.c_int32(0)
     _lib.check(plan.dev.lib.rk_solve_layout(C.byref(plan.cfg), _lib.MODE_FILTER, C.byref(lay)))
-    if lay.value != _lib.LAYOUT_TILE3:
+    if lay.value != _lib.LAYOUT_TILE3 or not tiles_ok:
         plan = cached_plan(*args, store_pred=True, batch_minor=True, **params)
     return plan
 
@@ -77,28 +93,22 @@ def solve_mv(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrog
         raise NotImplementedError                                   # fenrir.py:421-426
     if kalman_type != "standard":
         raise NotImplementedError("fenrir.solve_mv on the device: kalman_type='standard' only in this build")
-    obs = np.asarray(obs_data, dtype=np.float64)
-    D = np.asarray(obs_weight, dtype=np.float64)
-    Om = np.asarray(obs_var, dtype=np.float64)
-    if D.ndim != 4 or D.shape[2] != 1 or Om.shape != D.shape[:2] + (1, 1) or obs.shape != D.shape[:2] + (1,):
-        raise ValueError("fenrir: obs_data (n_obs, n_block, 1), obs_weight (n_obs, n_block, 1, n_bstate), obs_var "
-                         "(n_obs, n_block, 1, 1) -- scalar observations per block in this build")
+    obs, D, Om, n_bobs = _check_obs(obs_data, obs_weight, obs_var)
     ind = obs_index(t_min, t_max, n_steps, obs_times)
     if np.any(np.diff(ind) < 0):
         raise ValueError("obs_times must be ascending")
     from ..solve import SolvePlan
     plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
                      store_pred=True, batch_minor=True, **params)
-    if D.shape[1:] != (plan.d, 1, plan.p):
-        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, 1, {plan.p})")
+    if D.shape[1:] != (plan.d, n_bobs, plan.p):
+        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, n_bobs, {plan.p})")
     plan.filter(key)
     dev = plan.dev
-    d_obs, d_w, d_v, d_ind = (dev.to_device(np.ascontiguousarray(a)) for a in
-                              (obs[:, :, 0], D[:, :, 0, :], Om[:, :, 0, 0], ind.astype(np.int32)))
+    d_obs, d_w, d_v, d_ind = (dev.to_device(np.ascontiguousarray(a)) for a in (obs, D, Om, ind.astype(np.int32)))
     nbytes = C.c_size_t(0)
     _lib.check(dev.lib.rk_fenrir_workspace_bytes(C.byref(plan.cfg), C.byref(nbytes)))
     ws = dev.empty((nbytes.value // 8,))
     _lib.check(dev.lib.rk_fenrir_solve_mv(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(plan._out), d_obs.ptr,
-                                          d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), ws.ptr))
+                                          d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), n_bobs, ws.ptr))
     return plan.state_host()
 

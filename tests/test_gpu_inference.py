@@ -381,3 +381,42 @@ def test_fenrir_solve_mv_tiny_horizons(ra, N):
     m, v = fsolve(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
     mo, vo = ofen.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
     assert m.shape == (N + 1, 2, 3) and np.max(np.abs(m - mo)) < 1e-9 and np.max(np.abs(v - vo)) < 1e-9 * max(np.max(np.abs(vo)), 1e-300)
+
+
+@pytest.mark.parametrize("p,n_bobs", [(3, 2), (3, 3), (4, 2), (5, 3)])
+def test_fenrir_vector_observations(ra, p, n_bobs):
+    """n_bobs > 1 (src/rodeo/inference/fenrir.py:106-122): several observed linear combinations per block with a full
+    observation covariance -- LU update (utils.py:119) and the eigendecomposition log-density of utils.py:60-78 on the
+    device -- for inference.fenrir and for fenrir.solve_mv, single trajectory and batch, against the oracle (pinned by the
+    exact Gaussian likelihood, tests/test_oracle_fenrir.py)."""
+    from oracle import fenrir as ofen
+    from rodeo_amd.inference.fenrir import solve_mv as fsolve
+    N, t_max, B = 48, 2.4, 5
+    rng = np.random.default_rng(100 * p + n_bobs)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0 = init(np.array([-1., 1.]) + 0.05 * rng.standard_normal((B, 2)), 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / N, p, np.array([.1, .1]))
+    obs_times = np.array([0.0, 0.6, 1.2, 1.8, 2.4])
+    n_obs = len(obs_times)
+    Dw = 0.3 * rng.standard_normal((n_obs, 2, n_bobs, p)); Dw[:, :, 0, 0] += 1.0; Dw[:, :, 1, 1] += 1.0
+    a = 0.2 * rng.standard_normal((n_obs, 2, n_bobs, n_bobs))
+    Om = a @ np.swapaxes(a, -1, -2) + 0.05 * np.eye(n_bobs)
+    y = rng.standard_normal((n_obs, 2, n_bobs))
+    args = (W, x0, 0.0, t_max, N)
+    g, o = ra.interrogate.interrogate_kramer, oi.interrogate_kramer
+    val = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, prior, y, obs_times, Dw, Om, theta=theta)
+    ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, o, prior, y, obs_times, Dw, Om, theta=theta)
+    assert val.shape == (B,)
+    np.testing.assert_allclose(val, ref, rtol=1e-7, atol=1e-6)
+    one = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, W, x0[1], 0.0, t_max, N, g, prior, y, obs_times, Dw, Om, theta=theta[1])
+    assert isinstance(one, float) and abs(one - ref[1]) < 1e-6 * max(1.0, abs(ref[1]))
+    m, v = fsolve(None, ra.ode.fitzhugh_nagumo, *args, g, prior, y, obs_times, Dw, Om, theta=theta)
+    for b in (0, B - 1):
+        mo, vo = ofen.solve_mv(None, odes.fitzhugh_nagumo, W, x0[b], 0.0, t_max, N, o, prior, y, obs_times, Dw, Om, theta=theta[b])
+        scale = np.maximum(np.max(np.abs(mo), axis=(0, 1)), 1.0)
+        assert np.max(np.abs(m[b] - mo) / scale) < 1e-7
+        assert np.max(np.abs(v[b] - vo)) < 1e-6 * np.max(np.abs(vo))
+    with pytest.raises(NotImplementedError):
+        ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, prior, np.zeros((n_obs, 2, 4)), obs_times,
+                            np.zeros((n_obs, 2, 4, p)), np.zeros((n_obs, 2, 4, 4)), theta=theta)

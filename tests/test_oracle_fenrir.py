@@ -121,3 +121,45 @@ def test_fenrir_solve_mv_equals_exact_gaussian_posterior_for_a_linear_ode():
                               {"a": np.array([-1.0, 0.0, 0.0]), "f": lambda t: np.sin(2 * t)}, obs_ind, D, Om, y[:, 0, 0])
     np.testing.assert_allclose(m[0, 0], x0[0]); assert np.all(v[0] == 0)
     assert np.max(np.abs(m[1:, 0] - me)) < 1e-8 and np.max(np.abs(v[1:, 0] - ve)) < 1e-8
+
+
+def test_fenrir_vector_observations_equal_exact_gaussian_loglik():
+    """n_bobs = 2 (fenrir.py:106-122: obs_weight (n_obs, n_block, n_bobs, n_bstate), a full 2 x 2 obs_var): the restatement
+    against the exact Gaussian log-likelihood of the same linear model."""
+    from scipy.linalg import block_diag
+    N, t_min, t_max, p = 10, 0.0, 1.0, 3
+    W = np.array([[[0.0, 0.0, 1.0]]])
+    x0 = np.array([[-1.0, 0.0, 1.0]])
+    Q, R = priors.ibm_init((t_max - t_min) / N, p, np.array([0.5]))
+    obs_times = np.array([0.2, 0.5, 1.0])
+    obs_ind = np.searchsorted(np.linspace(t_min, t_max, N + 1), obs_times)
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal((3, 1, 2)) * 0.3
+    D2 = np.array([[1.0, 0.0, 0.0], [0.3, 1.0, 0.0]])
+    obs_weight = np.tile(D2[None, None], (3, 1, 1, 1))
+    Om2 = np.array([[0.05, 0.01], [0.01, 0.2]])
+    obs_var = np.tile(Om2[None, None], (3, 1, 1, 1))
+    val = ofen.fenrir(None, odes.higher_order, W, x0, t_min, t_max, N, oi.interrogate_kramer, (Q, R), y, obs_times,
+                      obs_weight, obs_var)
+    # exact: joint of X_1..X_N, conditioned on z = 0, then the 6 observations jointly
+    Qm, Rm = Q[0], R[0]
+    mean = np.zeros((N + 1, p)); mean[0] = x0[0]
+    cov = np.zeros((N + 1, N + 1, p, p))
+    for n in range(1, N + 1):
+        mean[n] = Qm @ mean[n - 1]
+        cov[n, n] = Qm @ cov[n - 1, n - 1] @ Qm.T + Rm
+        for k in range(n):
+            cov[n, k] = Qm @ cov[n - 1, k]; cov[k, n] = cov[n, k].T
+    mu = mean[1:].reshape(-1)
+    S = np.block([[cov[i, j] for j in range(1, N + 1)] for i in range(1, N + 1)])
+    ts = t_min + (t_max - t_min) * np.arange(1, N + 1) / N
+    Hz = np.zeros((N, N * p)); fz = np.sin(2 * ts)
+    for n in range(N):
+        Hz[n, n * p:(n + 1) * p] = W[0, 0] - np.array([-1.0, 0.0, 0.0])
+    K = S @ Hz.T @ np.linalg.inv(Hz @ S @ Hz.T)
+    mu_c, S_c = mu + K @ (fz - Hz @ mu), S - K @ Hz @ S
+    Hy = np.zeros((6, N * p))
+    for m, n in enumerate(obs_ind):
+        Hy[2 * m:2 * m + 2, (n - 1) * p:n * p] = D2
+    ref = multivariate_normal.logpdf(y.reshape(-1), Hy @ mu_c, Hy @ S_c @ Hy.T + block_diag(Om2, Om2, Om2), allow_singular=True)
+    assert abs(val - ref) < 1e-8 * max(1.0, abs(ref)), (val, ref)
