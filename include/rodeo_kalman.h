@@ -116,6 +116,12 @@ int         rk_profile_last(rk_handle h, int cap, const char** names, double* ms
  * rk_rhs_compile_check compiles without loading (needs no GPU) and reports compiler errors via rk_last_error().   */
 int rk_register_rhs_source(const char* type_name, const char* source, int32_t n_block, int32_t n_theta,
                            int32_t* rhs_id);
+/* the same for a right-hand side with n_bmeas > 1 measurements per block (src/rodeo/solve.py:48-51: ode_weight (n_block,
+ * n_bmeas, n_bstate)), e.g. the reference's "non-block" form of a small system (prior/indep_init.py, examples/solve_nb.py):
+ * `type_name` then names a type with the interface of csrc/solve_small_m_kernels.hpp (rk::AutoJacM<...> around a
+ * scalar-generic rhs writing out[D][M]); such right-hand sides run on the lane-per-trajectory kernels, n_bstate <= 9. */
+int rk_register_rhs_source_m(const char* type_name, const char* source, int32_t n_block, int32_t n_bmeas, int32_t n_theta,
+                             int32_t* rhs_id);
 int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate);
 
 /* ---- whole-solve boundary ---------------------------------------------------------------------------------

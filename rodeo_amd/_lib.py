@@ -79,6 +79,7 @@ SIGNATURES = {
     "rk_profile_enable": (C.c_int, [_H, C.c_int]),
     "rk_profile_last": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_D), C.POINTER(C.c_int)]),
     "rk_register_rhs_source": (C.c_int, [C.c_char_p, C.c_char_p, _I, _I, C.POINTER(_I)]),
+    "rk_register_rhs_source_m": (C.c_int, [C.c_char_p, C.c_char_p, _I, _I, _I, C.POINTER(C.c_int32)]),
     "rk_rhs_compile_check": (C.c_int, [_I, _I, _I]),
     "rk_solve_layout": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(_I)]),
     "rk_solve_sizes": (C.c_int, [C.POINTER(SolveCfg), _I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -22,7 +22,7 @@ namespace rk {
 struct UserRhs {
     std::string type_name;      // C++ type inside namespace rk, e.g. "MyOde" or "AutoJac<MyOde>"
     std::string source;
-    int n_block, n_theta;
+    int n_block, n_theta, n_bmeas;
 };
 
 static std::mutex g_mu;
@@ -36,6 +36,8 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
     if (kind == 2) snprintf(buf, sizeof buf, "rk::interrogate_kernel<rk::UserRhsT, %d, %d>", P, itg);
     else if (kind == 3) snprintf(buf, sizeof buf, "rk::fwd_tile3_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 3
     else if (kind == 4) snprintf(buf, sizeof buf, "rk::fwd_tile4_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 4
+    else if (kind == 7 || kind == 8)                                                                        // n_bmeas > 1
+        snprintf(buf, sizeof buf, "rk::fwd_kernel_m<rk::UserRhsT, %d, %d, %s>", P, itg, kind == 8 ? "true" : "false");
     else if (kind == 6) snprintf(buf, sizeof buf, "rk::fwd_sqrt_kernel<rk::UserRhsT, %d, %d>", P, itg);   // square-root filter
     else if (kind == 5) snprintf(buf, sizeof buf, "rk::fwd_tilen_kernel<rk::UserRhsT, %d, %d>", itg, P); // blocked tiles, P here = NB
     else snprintf(buf, sizeof buf, "rk::fwd_kernel<rk::UserRhsT, %d, %d, %s>", P, itg, kind == 1 ? "true" : "false");
@@ -46,7 +48,8 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
 static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<char>& code, std::string& lowered) {
     const std::string src = std::string("#include \"solve_small_kernels.hpp\"\n#include \"dual.hpp\"\n"
                                         "#include \"solve_tile3_kernels.hpp\"\n#include \"solve_tile4_kernels.hpp\"\n"
-                                        "#include \"solve_tilen_kernels.hpp\"\n#include \"solve_sqrt_kernels.hpp\"\nnamespace rk {\n") +
+                                        "#include \"solve_tilen_kernels.hpp\"\n#include \"solve_sqrt_kernels.hpp\"\n"
+                                        "#include \"solve_small_m_kernels.hpp\"\nnamespace rk {\n") +
                             u.source + "\nusing UserRhsT = " + u.type_name + ";\n}  // namespace rk\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rk_user_rhs.hip", kJitNumHeaders, kJitHeaderSources, kJitHeaderNames) !=
@@ -126,7 +129,7 @@ bool user_tile_available(const rk_solve_cfg* c, int which) {
     const int idx = c->rhs_id - RK_RHS_USER_BASE;
     if (idx < 0 || idx >= (int)g_rhs.size()) return false;
     const int nb = g_rhs[idx].n_block;
-    if (c->n_block != nb || c->n_bmeas != 1 || c->kalman_type != RK_KALMAN_STANDARD) return false;
+    if (c->n_block != nb || c->n_bmeas != 1 || g_rhs[idx].n_bmeas != 1 || c->kalman_type != RK_KALMAN_STANDARD) return false;
     if (nb < 1 || nb > (which == 4 ? 4 : 16)) return false;      // p = 3 and blocked tiles: up to 16 blocks (4 per wave, LDS exchange); p = 4: one wave
     // which = 5: the blocked tile kernel (solve_tilen_kernels.hpp), instantiated per NB = 1 (p = 4) / 2 (p = 5 .. 8)
     const int pkey = which == 5 ? (c->n_bstate <= 4 ? 1 : 2) : which;
@@ -159,8 +162,9 @@ int user_forward_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
         std::lock_guard<std::mutex> lk(g_mu);
         const int idx = c->rhs_id - RK_RHS_USER_BASE;
         RK_REQUIRE(idx >= 0 && idx < (int)g_rhs.size(), RK_ERR_INVALID, "unknown user rhs_id %d", c->rhs_id);
-        RK_REQUIRE(c->n_block == g_rhs[idx].n_block && c->n_bmeas == 1, RK_ERR_UNSUPPORTED,
-                   "user rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, g_rhs[idx].n_block, c->n_block, c->n_bmeas);
+        RK_REQUIRE(c->n_block == g_rhs[idx].n_block && c->n_bmeas == 1 && g_rhs[idx].n_bmeas == 1, RK_ERR_UNSUPPORTED,
+                   "square-root solver: user rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, g_rhs[idx].n_block,
+                   c->n_block, c->n_bmeas);
     }
     hipFunction_t fn;
     int rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, 6, &fn);
@@ -177,18 +181,28 @@ int user_rhs_check(const rk_solve_cfg* c) {
     std::lock_guard<std::mutex> lk(g_mu);
     const int idx = c->rhs_id - RK_RHS_USER_BASE;
     RK_REQUIRE(idx >= 0 && idx < (int)g_rhs.size(), RK_ERR_INVALID, "unknown user rhs_id %d", c->rhs_id);
-    RK_REQUIRE(c->n_block == g_rhs[idx].n_block && c->n_bmeas == 1, RK_ERR_UNSUPPORTED,
-               "user rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, g_rhs[idx].n_block, c->n_block, c->n_bmeas);
-    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 5, RK_ERR_UNSUPPORTED, "small-block path supports n_bstate in [2, 5], got %d",
-               c->n_bstate);
+    RK_REQUIRE(c->n_block == g_rhs[idx].n_block && c->n_bmeas == g_rhs[idx].n_bmeas, RK_ERR_UNSUPPORTED,
+               "user rhs %d needs n_block=%d, n_bmeas=%d (got %d, %d)", c->rhs_id, g_rhs[idx].n_block, g_rhs[idx].n_bmeas,
+               c->n_block, c->n_bmeas);
+    const int pmax = c->n_bmeas > 1 ? 9 : 5;                     // (the backward kernels exist up to n_bstate = 9)
+    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= pmax, RK_ERR_UNSUPPORTED, "lane-per-trajectory path supports n_bstate in [2, %d] "
+               "here, got %d", pmax, c->n_bstate);
+    RK_REQUIRE(c->n_bmeas <= c->n_bstate, RK_ERR_INVALID, "n_bmeas = %d exceeds n_bstate = %d", c->n_bmeas, c->n_bstate);
     return RK_OK;
+}
+
+static int user_n_bmeas(int rhs_id) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int idx = rhs_id - RK_RHS_USER_BASE;
+    return idx >= 0 && idx < (int)g_rhs.size() ? g_rhs[idx].n_bmeas : 1;
 }
 
 int user_forward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
     int rc = user_rhs_check(c);
     if (rc) return rc;
     hipFunction_t fn;
-    rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, (c->flags & RK_FLAG_STORE_PRED) ? 1 : 0, &fn);
+    const bool sp = (c->flags & RK_FLAG_STORE_PRED) != 0;
+    rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, user_n_bmeas(c->rhs_id) > 1 ? (sp ? 8 : 7) : (sp ? 1 : 0), &fn);
     if (rc) return rc;
     SolveArgs args = a;
     void* params[] = {&args};
@@ -202,6 +216,7 @@ int user_interrogate(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, dou
                      const double* vp, double* wm, double* mm_, double* vm) {
     int rc = user_rhs_check(c);
     if (rc) return rc;
+    RK_REQUIRE(c->n_bmeas == 1, RK_ERR_UNSUPPORTED, "rk_interrogate_batched: n_bmeas = 1 only (n_bmeas > 1 runs fused in the solvers)");
     hipFunction_t fn;
     rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, 2, &fn);
     if (rc) return rc;
@@ -217,13 +232,19 @@ using namespace rk;
 
 extern "C" {
 
-int rk_register_rhs_source(const char* type_name, const char* source, int32_t n_block, int32_t n_theta, int32_t* rhs_id) {
+int rk_register_rhs_source_m(const char* type_name, const char* source, int32_t n_block, int32_t n_bmeas, int32_t n_theta,
+                             int32_t* rhs_id) {
     RK_REQUIRE(type_name && source && rhs_id, RK_ERR_INVALID, "rk_register_rhs_source: null argument");
-    RK_REQUIRE(n_block >= 1 && n_block <= 16 && n_theta >= 0, RK_ERR_INVALID, "rk_register_rhs_source: bad n_block / n_theta");
+    RK_REQUIRE(n_block >= 1 && n_block <= 16 && n_theta >= 0 && n_bmeas >= 1 && n_bmeas <= 4, RK_ERR_INVALID,
+               "rk_register_rhs_source: bad n_block / n_bmeas / n_theta");
     std::lock_guard<std::mutex> lk(g_mu);
-    g_rhs.push_back(UserRhs{type_name, source, n_block, n_theta});
+    g_rhs.push_back(UserRhs{type_name, source, n_block, n_theta, n_bmeas});
     *rhs_id = RK_RHS_USER_BASE + (int)g_rhs.size() - 1;
     return RK_OK;
+}
+
+int rk_register_rhs_source(const char* type_name, const char* source, int32_t n_block, int32_t n_theta, int32_t* rhs_id) {
+    return rk_register_rhs_source_m(type_name, source, n_block, 1, n_theta, rhs_id);
 }
 
 int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate) {
@@ -236,7 +257,7 @@ int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate) 
     }
     std::vector<char> code;
     std::string lowered;
-    return jit_compile(u, n_bstate, interrogate, 0, code, lowered);
+    return jit_compile(u, n_bstate, interrogate, u.n_bmeas > 1 ? 7 : 0, code, lowered);
 }
 
 }  // extern "C"

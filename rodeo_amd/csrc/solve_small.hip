@@ -531,9 +531,9 @@ static int small_backward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a
         else hipLaunchKernelGGL((bwd_mv_kernel<P_>), grid, block, 0, h->stream, a);             \
         break;
     switch (c->n_bstate) {
-        RK_BWD(2) RK_BWD(3) RK_BWD(4) RK_BWD(5)
+        RK_BWD(2) RK_BWD(3) RK_BWD(4) RK_BWD(5) RK_BWD(6) RK_BWD(7) RK_BWD(8) RK_BWD(9)
         default:
-            set_error("small-block path supports n_bstate in [2, 5], got %d", c->n_bstate);
+            set_error("small-block path supports n_bstate in [2, 9] for the backward pass, got %d", c->n_bstate);
             return RK_ERR_UNSUPPORTED;
     }
 #undef RK_BWD

@@ -114,7 +114,7 @@ def linear_dense(n_vars, n_deriv):
     return ode
 
 
-def from_source(type_name, source, n_block, param_spec=(), host_fun=None, name=None):
+def from_source(type_name, source, n_block, param_spec=(), host_fun=None, name=None, n_bmeas=1):
     """
     Register an ODE that is not built in, from HIP source (compiled with hiprtc on first use).
 
@@ -124,19 +124,21 @@ def from_source(type_name, source, n_block, param_spec=(), host_fun=None, name=N
     Jacobian that ``interrogate_kramer`` needs (``jax.jacfwd`` in src/rodeo/interrogate.py:76-79) comes from
     forward-mode dual numbers (rodeo_amd/csrc/dual.hpp).  ``param_spec`` = ((kwarg name, size), ...) fixes how
     ``**params`` are packed into ``th[]``; ``host_fun(X, t, **params)`` is the NumPy twin used only for host-side input
-    preparation (``first_order_pad``).  n_bmeas = 1, kalman_type "standard".
+    preparation (``first_order_pad``).  ``n_bmeas`` > 1 (several measurements per block, src/rodeo/solve.py:48-51): the
+    source follows csrc/solve_small_m_kernels.hpp (``static constexpr int M``, ``rhs`` writing ``out[D][M]``, wrapped as
+    ``AutoJacM<Name>``) and runs on the lane-per-trajectory kernels with the standard filter.
     """
     import ctypes as C
     lib = _lib.load()
     rid = C.c_int32(0)
     n_theta = sum(s for _, s in param_spec)
-    _lib.check(lib.rk_register_rhs_source(type_name.encode(), source.encode(), int(n_block), max(int(n_theta), 0),
-                                          C.byref(rid)))
+    _lib.check(lib.rk_register_rhs_source_m(type_name.encode(), source.encode(), int(n_block), int(n_bmeas),
+                                            max(int(n_theta), 0), C.byref(rid)))
 
     def _no_host(X, t, **params):
         raise TypeError(f"ODE '{name or type_name}' was registered without a host_fun; it cannot be evaluated on the host")
 
-    return DeviceODE(name or type_name, rid.value, int(n_block), 1, param_spec, host_fun or _no_host)
+    return DeviceODE(name or type_name, rid.value, int(n_block), int(n_bmeas), param_spec, host_fun or _no_host)
 
 
 def from_python(fun, n_vars, n_deriv_used=2, name=None, **param_sizes):

@@ -111,7 +111,9 @@ def _symbols(shape, fmt):
 
 
 def trace_source(fun, n_vars, n_deriv_used, param_spec, struct_name):
-    """Run ``fun`` on symbols; returns (source, ndep).  ``param_spec`` = ((name, size), ...)."""
+    """Run ``fun`` on symbols; returns (source, ndep, n_bmeas).  ``param_spec`` = ((name, size), ...).  A function that
+    returns (n_vars, M) with M > 1 (several measurements per block, src/rodeo/solve.py:48-51 -- e.g. the "non-block" form
+    of a small system) yields a struct with ``out[D][M]`` for ``rk::AutoJacM`` (csrc/solve_small_m_kernels.hpp)."""
     X = _symbols((n_vars, n_deriv_used), lambda b, j: f"X[{b}][{j}]")
     params, off = {}, 0
     for name, size in param_spec:
@@ -121,44 +123,48 @@ def trace_source(fun, n_vars, n_deriv_used, param_spec, struct_name):
     out = np.asarray(out, dtype=object)
     if out.shape == (n_vars,):
         out = out[:, None]
-    if out.shape != (n_vars, 1):
-        raise ValueError(f"the traced ode_fun must return shape ({n_vars}, 1) (one measurement per variable), got {out.shape}")
+    if out.ndim != 2 or out.shape[0] != n_vars or not 1 <= out.shape[1] <= 4:
+        raise ValueError(f"the traced ode_fun must return shape ({n_vars}, n_bmeas) with n_bmeas in 1..4, got {out.shape}")
+    n_bmeas = out.shape[1]
     lines = []
     for b in range(n_vars):
-        lines.append(f"        out[{b}] = {Sym._c(out[b, 0])};")
+        for i in range(n_bmeas):
+            lines.append(f"        out[{b}]{'[%d]' % i if n_bmeas > 1 else ''} = {Sym._c(out[b, i])};")
     body = "\n".join(lines)
     used = [j for b in range(n_vars) for j in range(n_deriv_used) if f"X[{b}][{j}]" in body]
     ndep = max(used) + 1 if used else 1
     n_theta = max(off, 0)
+    out_t = "T (&out)[D][M]" if n_bmeas > 1 else "T (&out)[D]"
+    m_line = f"\n    static constexpr int M = {n_bmeas};" if n_bmeas > 1 else ""
     src = f"""
 // generated by rodeo_amd.trace from the Python function {getattr(fun, '__name__', 'ode_fun')!r}
 struct {struct_name} {{
-    static constexpr int D = {n_vars};
+    static constexpr int D = {n_vars};{m_line}
     static constexpr int NTHETA = {max(n_theta, 1)};
     static constexpr int NDEP = {ndep};
     template <class T, int P>
-    __device__ __forceinline__ static void rhs(const T (&X)[D][P], double t, const double (&th)[NTHETA], T (&out)[D]) {{
+    __device__ __forceinline__ static void rhs(const T (&X)[D][P], double t, const double (&th)[NTHETA], {out_t}) {{
         static_assert(P >= NDEP, "the right-hand side reads more derivatives than the prior carries");
 {body}
     }}
 }};
 """
-    return src, ndep
+    return src, ndep, n_bmeas
 
 
-def _host_twin(fun, n_vars):
+def _host_twin(fun, n_vars, n_bmeas=1):
     """The Python function itself, vectorised over leading batch axes of X and of the parameters."""
     def host(X, t, **params):
         X = np.asarray(X, dtype=np.float64)
         if X.ndim == 2 and all(np.ndim(v) <= 1 for v in params.values()):
-            return np.asarray(fun(X, t, **params), dtype=np.float64).reshape(n_vars, 1)
+            return np.asarray(fun(X, t, **params), dtype=np.float64).reshape(n_vars, n_bmeas)
         lead = np.broadcast_shapes(X.shape[:-2], *[np.shape(v)[:-1] for v in params.values() if np.ndim(v) >= 2])
         Xb = np.broadcast_to(X, lead + X.shape[-2:])
         pb = {k: (np.broadcast_to(v, lead + np.shape(v)[-1:]) if np.ndim(v) >= 2 else v) for k, v in params.items()}
-        out = np.empty(lead + (n_vars, 1))
+        out = np.empty(lead + (n_vars, n_bmeas))
         for idx in np.ndindex(*lead):
             out[idx] = np.asarray(fun(Xb[idx], t, **{k: (v[idx] if np.ndim(v) >= 2 else v) for k, v in pb.items()}),
-                                  dtype=np.float64).reshape(n_vars, 1)
+                                  dtype=np.float64).reshape(n_vars, n_bmeas)
         return out
     return host
 
@@ -168,8 +174,8 @@ _cache = {}
 
 def from_python(fun, n_vars, n_deriv_used=2, name=None, **param_sizes):
     """
-    ``DeviceODE`` from an ordinary Python right-hand side ``fun(X, t, **params)`` (X of shape (n_vars, n_deriv),
-    return shape (n_vars, 1)).  ``param_sizes``: keyword -> length of that parameter vector, e.g. ``theta=3``.
+    ``DeviceODE`` from an ordinary Python right-hand side ``fun(X, t, **params)`` (X of shape (n_block, n_bstate),
+    return shape (n_block, n_bmeas); here ``n_vars`` = n_block).  ``param_sizes``: keyword -> length of that parameter vector, e.g. ``theta=3``.
     ``n_deriv_used``: how many leading derivatives the function may read (first-order ODEs read X[:, 0] only).
     """
     from . import ode
@@ -177,12 +183,13 @@ def from_python(fun, n_vars, n_deriv_used=2, name=None, **param_sizes):
     key = (fun, int(n_vars), int(n_deriv_used), spec)
     if key in _cache:
         return _cache[key]
-    probe_src, _ = trace_source(fun, n_vars, n_deriv_used, spec, "TracedOde")
+    probe_src, _, _ = trace_source(fun, n_vars, n_deriv_used, spec, "TracedOde")
     tag = hashlib.sha1(probe_src.encode()).hexdigest()[:10]
     struct = f"Traced_{tag}"
-    src, ndep = trace_source(fun, n_vars, n_deriv_used, spec, struct)
-    dev = ode.from_source(f"AutoJac<{struct}>", src, n_vars, spec, _host_twin(fun, n_vars),
-                          name=name or getattr(fun, "__name__", struct))
+    src, ndep, n_bmeas = trace_source(fun, n_vars, n_deriv_used, spec, struct)
+    wrapper = "AutoJacM" if n_bmeas > 1 else "AutoJac"
+    dev = ode.from_source(f"{wrapper}<{struct}>", src, n_vars, spec, _host_twin(fun, n_vars, n_bmeas),
+                          name=name or getattr(fun, "__name__", struct), n_bmeas=n_bmeas)
     dev.source, dev.ndep = src, ndep
     _cache[key] = dev
     return dev

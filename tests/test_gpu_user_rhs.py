@@ -425,3 +425,89 @@ def test_traced_function_reading_a_derivative(ra):
     t = np.linspace(0, t_max, N + 1)
     exact = np.exp(-0.15 * t) * (np.cos(w * t) + 0.15 / w * np.sin(w * t))
     assert np.max(np.abs(m[:, 0, 0] - exact)) < 5e-3
+
+
+def test_several_measurements_per_block_non_block_form(ra):
+    """n_bmeas > 1 (src/rodeo/solve.py:48-51 is general in it): FitzHugh-Nagumo in the reference's NON-BLOCK form
+    (prior.indep_init merges the two variables' priors into one block of 6 states; ode_weight (1, 2, 6); examples/
+    solve_nb.py, examples/timings.py:209) as an ordinary Python function returning (1, 2), traced and compiled; and a
+    two-block system with two measurements each.  All four interrogations, solve_mv / solve_sim / the filter, against the
+    oracle (complex-step block Jacobian), batch with per-trajectory parameters."""
+    from scipy.linalg import block_diag
+    from rodeo_amd import _lib
+
+    def fitz_nb(X, t, theta):
+        a, b, c = theta
+        V, R = X[0, 0], X[0, 3]
+        return np.array([[c * (V - V * V * V / 3 + R), -1 / c * (V - a + b * R)]])
+
+    def host(X, t, theta):
+        th = np.asarray(theta, dtype=np.float64)
+        a, b, c = th[..., 0], th[..., 1], th[..., 2]
+        V, R = X[..., 0, 0], X[..., 0, 3]
+        return np.stack([c * (V - V * V * V / 3 + R), -1 / c * (V - a + b * R)], axis=-1)[..., None, :]
+    o_ode = odes.ODE("fitz_nb", 1, 2, host, lambda X, t, theta: odes.complex_step_blockjac(
+        odes.ODE("tmp", 1, 2, host, None), X, t, theta=theta))
+    B, N, t_max, n_deriv = 5, 40, 2.0, 3
+    rng = np.random.default_rng(3)
+    theta = np.array([.2, .2, 3.]) * np.exp(0.1 * rng.standard_normal((B, 3)))
+    Wb, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, n_deriv)
+    W = block_diag(*Wb)[None]                                               # (1, 2, 6)
+    x0 = init(np.array([-1., 1.]) + 0.1 * rng.standard_normal((B, 2)), 0.0, theta=theta).reshape(B, 1, 6)
+    prior = ra.indep_init(ra.ibm_init(t_max / N, n_deriv, np.array([.1, .1])))
+    assert prior[0].shape == (1, 6, 6)
+    args = (W, x0, 0.0, t_max, N)
+    # With an exact measurement (var_meas = 0: kramer, schober) the reference's covariance-form recursion is itself unstable
+    # in the non-block form (the oracle's filtered variances lose definiteness within a few steps and two Jacobian
+    # implementations of the SAME function drive it to different answers -- DESIGN.md section 2, "numerical finding"), so
+    # those two are compared over the first steps and the regularised ones (var_meas = W Sigma- W^T) over the horizon.
+    for name in ("kramer", "rodeo", "schober", "chkrebtii"):
+        g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+        if name == "chkrebtii":
+            g, o = functools.partial(g, kalman_type="standard"), functools.partial(o, kalman_type="standard")
+        Nn = 4 if name in ("kramer", "schober") else N
+        a_n = (W, x0, 0.0, t_max * Nn / N, Nn)
+        plan = ra.SolvePlan(fitz_nb, *a_n, g, prior, theta=theta)
+        plan.mv(11)
+        assert plan.layout == _lib.LAYOUT_BATCH_MINOR and plan.m == 2
+        m, v = plan.state_host()
+        mo, vo = scan.solve_mv(11, o_ode, *a_n, o, prior, theta=theta)
+        scale = np.maximum(np.max(np.abs(mo), axis=(0, 1, 2)), 1.0)
+        assert m.shape == (B, Nn + 1, 1, 6) and np.max(np.abs(m - mo) / scale) < 1e-8, name
+        assert np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo)), name
+    x = ra.solve_sim(4, fitz_nb, *args, ra.interrogate.interrogate_rodeo, prior, theta=theta)
+    xo = scan.solve_sim(4, o_ode, *args, oi.interrogate_rodeo, prior, theta=theta)
+    assert np.max(np.abs(x - xo) / np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1.0)) < 1e-6
+    filt = ra.solve._solve_filter(None, fitz_nb, *args, ra.interrogate.interrogate_rodeo, *prior, theta=theta)
+    fo = scan.solve_filter(None, o_ode, *args, oi.interrogate_rodeo, *prior, theta=theta)
+    for key in ("state_pred", "state_filt"):
+        assert np.max(np.abs(filt[key][0] - fo[key][0])) < 1e-8 * max(1.0, np.max(np.abs(fo[key][0])))
+    # the non-block form keeps the cross-variable Jacobian that the block form drops (interrogate.py:70): with kramer
+    # the two forms differ, with schober (no Jacobian) they give the same means for the shared components
+    mb, _ = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, Wb, x0.reshape(B, 2, 3), 0.0, t_max, N, ra.interrogate.interrogate_schober,
+                        ra.ibm_init(t_max / N, n_deriv, np.array([.1, .1])), theta=theta)
+    mn, _ = ra.solve_mv(None, fitz_nb, *args, ra.interrogate.interrogate_schober, prior, theta=theta)
+    assert np.max(np.abs(mn.reshape(B, N + 1, 2, 3) - mb)) < 1e-9
+
+    # two blocks with two measurements each (n_bstate = 4: (x, x', y, y') per block)
+    def two(X, t, k):
+        return np.array([[-k[0] * X[0, 0] + X[1, 2], np.sin(X[0, 0]) - X[0, 2]],
+                         [-k[1] * X[1, 0] * X[0, 2], X[0, 0] - X[1, 2]]])
+
+    def host2(X, t, k):
+        kk = np.asarray(k, dtype=np.float64)
+        return np.stack([np.stack([-kk[..., 0] * X[..., 0, 0] + X[..., 1, 2], np.sin(X[..., 0, 0]) - X[..., 0, 2]], axis=-1),
+                         np.stack([-kk[..., 1] * X[..., 1, 0] * X[..., 0, 2], X[..., 0, 0] - X[..., 1, 2]], axis=-1)], axis=-2)
+    o2 = odes.ODE("two", 2, 2, host2, lambda X, t, k: odes.complex_step_blockjac(odes.ODE("t", 2, 2, host2, None), X, t, k=k))
+    W2 = np.zeros((2, 2, 4)); W2[:, 0, 1] = 1.0; W2[:, 1, 3] = 1.0
+    k = np.array([0.7, 1.3]) * np.exp(0.05 * rng.standard_normal((B, 2)))
+    x2 = np.zeros((B, 2, 4)); x2[..., 0] = 1.0 + 0.1 * rng.standard_normal((B, 2)); x2[..., 2] = 0.5
+    f0 = host2(x2, 0.0, k)
+    x2[..., 1], x2[..., 3] = f0[..., 0], f0[..., 1]
+    Q1, R1 = ra.ibm_init(1.0 / 30, 2, np.array([.1, .1, .1, .1]))
+    pr2 = (np.stack([block_diag(Q1[0], Q1[1]), block_diag(Q1[2], Q1[3])]), np.stack([block_diag(R1[0], R1[1]), block_diag(R1[2], R1[3])]))
+    for name, N2 in (("kramer", 4), ("rodeo", 30)):
+        g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+        m, v = ra.solve_mv(None, two, W2, x2, 0.0, N2 / 30.0, N2, g, pr2, k=k)
+        mo, vo = scan.solve_mv(None, o2, W2, x2, 0.0, N2 / 30.0, N2, o, pr2, k=k)
+        assert np.max(np.abs(m - mo)) < 1e-8 * max(1.0, np.max(np.abs(mo))) and np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))

@@ -80,13 +80,13 @@ def test_trace_python_rhs_to_source_and_compile():
         a, b, c = params["theta"]
         V, R = X[:, 0]
         return np.array([[c * (V - V * V * V / 3 + R)], [-1 / c * (V - a + b * R)]])
-    src, ndep = trace.trace_source(fitz_fun, 2, 2, (("theta", 3),), "Probe")
+    src, ndep, _ = trace.trace_source(fitz_fun, 2, 2, (("theta", 3),), "Probe")
     assert ndep == 1 and "static constexpr int D = 2;" in src and "NTHETA = 3" in src
     assert "out[0] = (th[2] * ((X[0][0] - (((X[0][0] * X[0][0]) * X[0][0]) / 3.0)) + X[1][0]));" in src
 
     def second(X, t, k):
         return np.array([[np.sin(2 * t) - k[0] * X[0, 0] - 0.1 * X[0, 1] ** 3 + np.exp(-X[0, 0] ** 2) + np.sqrt(1.0 + X[0, 0] ** 2)]])
-    src2, ndep2 = trace.trace_source(second, 1, 2, (("k", 1),), "Probe2")
+    src2, ndep2, _ = trace.trace_source(second, 1, 2, (("k", 1),), "Probe2")
     assert ndep2 == 2 and "sin((2.0 * t))" in src2 and "exp(" in src2 and "sqrt(" in src2
     ode = ra.ode.from_python(fitz_fun, 2, theta=3)
     assert ra.ode.from_python(fitz_fun, 2, theta=3) is ode                    # cached
