@@ -17,6 +17,7 @@
 // Workspace record of item (n, unit), RS doubles (padded to even):
 //     solve_mv :  [ G^T row-major (p*p) | Sigma-_{n+1} (p*p) | mu-_{n+1} (p) ]
 //     solve_sim:  [ G^T row-major (p*p) | mu-_{n+1} (p)      | mu_f + L z (p) ]      (n = N: G = 0, mu- = 0: the terminal draw)
+#include <cstdlib>
 #include "common.hpp"
 #include "kalman_small.hpp"
 #include "mfma_tile.hpp"
@@ -39,7 +40,7 @@ __host__ __device__ inline int tilen_rs(int p, bool sim) {
 // side -- lane-strided global accesses touch 64 cache lines per instruction.
 template <int P, bool SIM>
 __global__ void __launch_bounds__(64) tilen_gain_kernel(SolveArgs a, const double* __restrict__ tiles, double* __restrict__ ws,
-                                                        int blocks_per_step) {
+                                                        int blocks_per_step, int n_first) {
     constexpr int PP = P * P + P;
     constexpr int RS0 = SIM ? P * P + 2 * P : 2 * P * P + P, RS = RS0 + (RS0 & 1);
     constexpr bool STAGED = P <= 6;                                  // beyond that the staging registers only add spills (measured)
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(64) tilen_gain_kernel(SolveArgs a, const doubl
     const int step_idx = blockIdx.x / blocks_per_step;
     const int tau0 = (blockIdx.x - step_idx * blocks_per_step) * 64;
     const int n_here = n_units - tau0 < 64 ? n_units - tau0 : 64;
-    const int n = step_idx + 1;                                      // mv: 1 .. N-1 ; sim: 1 .. N
+    const int n = step_idx + n_first;                                // mv: 1 .. N-1 ; sim: 1 .. N (this launch: n_first ..)
     const bool live = lane < n_here;
     const int tau = live ? tau0 + lane : n_units - 1;
     const int b = tau / D, blk = tau - b * D;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(64) tilen_gain_kernel(SolveArgs a, const doubl
 // All accesses are raw buffer loads / stores on a window over the wave's four units of one time row: lanes of the zero
 // padding (and of units past the end) carry an out-of-range offset, so their loads return 0.0 and their stores are
 // dropped -- no selects and no exec-mask branches in the step.
-constexpr int TN_RING = 8;
+constexpr int TN_RING = 4;        // (22 memory operations per step at NB = 2: the 6-bit vmcnt covers about three steps anyway)
 constexpr int TN_OOR = (int)0x80000000;
 
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t rs, int off) {
@@ -174,8 +175,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_window(const void* base, i
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
 
+// At most 256 VGPRs (waves_per_eu): two chain waves per SIMD at larger batches.
 template <int NB>
-__global__ void __launch_bounds__(64) bwd_mv_tilen_kernel(SolveArgs a, double* __restrict__ tiles, const double* __restrict__ ws, int P) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+bwd_mv_tilen_kernel(SolveArgs a, double* __restrict__ tiles, const double* __restrict__ ws, int P,
+                                                          int n_top, int n_bot) {
     const int n_units = a.B * a.D, PP = P * P + P, RS = tilen_rs(P, false);
     const int lane = threadIdx.x, r = lane >> 4, g = (lane >> 2) & 3, c = lane & 3;
     const bool valid = blockIdx.x * 4 + g < n_units;
@@ -201,10 +205,11 @@ __global__ void __launch_bounds__(64) bwd_mv_tilen_kernel(SolveArgs a, double* _
     const double* const tw = tiles + (size_t)blockIdx.x * 4 * PP;
     const double* const ww = ws + (size_t)blockIdx.x * 4 * RS;
     const int tbytes = 4 * PP * 8, wbytes = 4 * RS * 8;
-    // carry = filt[N] (solve.py:279-282)
+    // this launch smooths the steps n_top .. n_bot (descending); its carry is the tile of step n_top + 1: filt[N] for the
+    // first chunk (solve.py:279-282), the smoothed state the previous chunk's launch left there otherwise
     double Ms[NB][NB], ms[NB];
     {
-        const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)a.N * tstride, tbytes);
+        const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)(n_top + 1) * tstride, tbytes);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             ms[k] = buf_ld(t, oM[k]);
@@ -247,25 +252,25 @@ __global__ void __launch_bounds__(64) bwd_mv_tilen_kernel(SolveArgs a, double* _
             for (int bb = 0; bb < NB; ++bb) buf_st(Ms[k][bb], t, oS[k][bb]);
         }
     };
-    // steps n = N-1 .. 1 through a ring of TN_RING records: slot s is consumed and at once refilled with the record
+    // steps n_top .. n_bot through a ring of TN_RING records: slot s is consumed and at once refilled with the record
     // TN_RING steps further down, so TN_RING - 1 steps of loads are in flight all the time, also across loop iterations
-    // (indices below 1 are clamped: a harmless reload of step 1 that is never consumed)
-    int n = a.N - 1;
+    // (indices below n_bot are clamped: a harmless reload that is never consumed)
+    int n = n_top;
     Rec q[TN_RING];
 #pragma unroll
-    for (int s = 0; s < TN_RING; ++s) load(n - s >= 1 ? n - s : 1, q[s]);
-    while (n >= TN_RING) {
+    for (int s = 0; s < TN_RING; ++s) load(n - s >= n_bot ? n - s : n_bot, q[s]);
+    while (n - n_bot + 1 >= TN_RING) {
 #pragma unroll
         for (int s = 0; s < TN_RING; ++s) {
             step(n - s, q[s]);
             const int nn = n - s - TN_RING;
-            load(nn >= 1 ? nn : 1, q[s]);
+            load(nn >= n_bot ? nn : n_bot, q[s]);
         }
         n -= TN_RING;
     }
 #pragma unroll
     for (int s = 0; s < TN_RING; ++s)
-        if (s < n) step(n - s, q[s]);                     // (uniform condition)
+        if (s < n - n_bot + 1) step(n - s, q[s]);         // (uniform condition)
 }
 
 template <int NB>
@@ -405,7 +410,7 @@ int tilen_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
                RK_ERR_UNSUPPORTED, "blocked tile path: n_traj * n_block too large for 32-bit record offsets");
     if (mode != RK_MODE_FILTER) {
         const size_t need = tilen_ws_doubles(c, mode) * sizeof(double);
-        RK_REQUIRE(ws && ws_bytes >= need, RK_ERR_INVALID,
+        RK_REQUIRE(need == 0 || (ws && ws_bytes >= need), RK_ERR_INVALID,
                    "blocked tile path: out->workspace_bytes = %zu, this call needs %zu (rk_solve_workspace_bytes)", ws_bytes, need);
     }
     int rc;
@@ -415,35 +420,59 @@ int tilen_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     else rc = launch_fwd_tilen<HigherOrder>(h, c, a, tiles);
     if (rc || mode == RK_MODE_FILTER) return rc;
     const bool sim = mode == RK_MODE_SIM;
-    const int n_items_t = sim ? a.N : a.N - 1;            // time steps with an item: n = 1 .. N (sim) / N-1 (mv)
-    if (n_items_t >= 1) {
-        const int bps = div_up(n_units, 64);
-        RK_REQUIRE((size_t)bps * (size_t)n_items_t < 0x7fffffffull, RK_ERR_UNSUPPORTED,
+    const int bps = div_up(n_units, 64);
+    auto launch_gain = [&](hipStream_t st, int n_first, int n_count) -> int {
+        RK_REQUIRE((size_t)bps * (size_t)n_count < 0x7fffffffull, RK_ERR_UNSUPPORTED,
                    "blocked tile path: n_steps * n_traj * n_block too large for one launch");
-        const dim3 grid((unsigned)(bps * n_items_t)), block(64);
-        LaunchTimer t(h, sim ? "tilen_gain_kernel<sim>" : "tilen_gain_kernel");
+        const dim3 grid((unsigned)(bps * n_count)), block(64);
 #define RK_GAIN(P_)                                                                                     \
     case P_:                                                                                            \
-        if (sim) hipLaunchKernelGGL((tilen_gain_kernel<P_, true>), grid, block, 0, h->stream, a, tiles, ws, bps);   \
-        else hipLaunchKernelGGL((tilen_gain_kernel<P_, false>), grid, block, 0, h->stream, a, tiles, ws, bps);      \
+        if (sim) hipLaunchKernelGGL((tilen_gain_kernel<P_, true>), grid, block, 0, st, a, tiles, ws, bps, n_first);   \
+        else hipLaunchKernelGGL((tilen_gain_kernel<P_, false>), grid, block, 0, st, a, tiles, ws, bps, n_first);      \
         break;
         switch (P) { RK_GAIN(4) RK_GAIN(5) RK_GAIN(6) RK_GAIN(7) RK_GAIN(8) }
 #undef RK_GAIN
+        RK_HIP(hipGetLastError());
+        return RK_OK;
+    };
+    const dim3 cgrid(div_up(n_units, 4)), cblock(64);
+    if (sim) {
+        {
+            LaunchTimer t(h, "tilen_gain_kernel<sim>");
+            rc = launch_gain(h->stream, 1, a.N);
+            t.stop();
+            if (rc) return rc;
+        }
+        LaunchTimer t(h, "bwd_sim_tilen_kernel");
+        if (tilen_nb(P) == 1) hipLaunchKernelGGL((bwd_sim_tilen_kernel<1>), cgrid, cblock, 0, h->stream, a, tiles, ws, P);
+        else hipLaunchKernelGGL((bwd_sim_tilen_kernel<2>), cgrid, cblock, 0, h->stream, a, tiles, ws, P);
         t.stop();
         RK_HIP(hipGetLastError());
+        return RK_OK;
     }
-    const dim3 grid(div_up(n_units, 4)), block(64);
-    LaunchTimer t(h, sim ? "bwd_sim_tilen_kernel" : "bwd_mv_tilen_kernel");
-    if (sim) {
-        if (tilen_nb(P) == 1) hipLaunchKernelGGL((bwd_sim_tilen_kernel<1>), grid, block, 0, h->stream, a, tiles, ws, P);
-        else hipLaunchKernelGGL((bwd_sim_tilen_kernel<2>), grid, block, 0, h->stream, a, tiles, ws, P);
-    } else if (a.N >= 2) {
-        if (tilen_nb(P) == 1) hipLaunchKernelGGL((bwd_mv_tilen_kernel<1>), grid, block, 0, h->stream, a, tiles, ws, P);
-        else hipLaunchKernelGGL((bwd_mv_tilen_kernel<2>), grid, block, 0, h->stream, a, tiles, ws, P);
+    if (a.N < 2) return RK_OK;
+    const int steps = a.N - 1;
+    auto launch_chain = [&](int n_top, int n_bot) -> int {
+        if (tilen_nb(P) == 1) hipLaunchKernelGGL((bwd_mv_tilen_kernel<1>), cgrid, cblock, 0, h->stream, a, tiles, ws, P, n_top, n_bot);
+        else hipLaunchKernelGGL((bwd_mv_tilen_kernel<2>), cgrid, cblock, 0, h->stream, a, tiles, ws, P, n_top, n_bot);
+        RK_HIP(hipGetLastError());
+        return RK_OK;
+    };
+    // (Tried: the chain and the gain items of the next time chunk overlapped on two streams -- the chain is latency-bound
+    // on one wave per SIMD -- measured 2.84 ms against 3.02 ms sequential at n_deriv = 5 and slower at 6: the gain grid's
+    // workgroups take every free slot and the two kernels mostly alternate.  A fused producer / consumer workgroup like the
+    // p = 3 kernels: 2.76 ms at n_deriv = 5, 5.1 ms at 6 -- its producers need > 256 VGPRs, so one workgroup per CU and
+    // two rounds; capped at 256 VGPRs they spill: 4.9 ms.  Both removed.)
+    {
+        LaunchTimer t(h, "tilen_gain_kernel");
+        rc = launch_gain(h->stream, 1, steps);
+        t.stop();
+        if (rc) return rc;
     }
+    LaunchTimer t(h, "bwd_mv_tilen_kernel");
+    rc = launch_chain(a.N - 1, 1);
     t.stop();
-    RK_HIP(hipGetLastError());
-    return RK_OK;
+    return rc;
 }
 
 }  // namespace rk

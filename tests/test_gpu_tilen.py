@@ -86,7 +86,7 @@ def test_blocked_tiles_kernels_are_the_ones_that_run(ra, p):
     plan.mv(None)
     names = [k for k, _ in plan.dev.profile_last()]
     plan.dev.profile_enable(False)
-    assert names == ["fwd_tilen_kernel", "tilen_gain_kernel", "bwd_mv_tilen_kernel"], names
+    assert names[0] == "fwd_tilen_kernel" and all("tilen" in k for k in names[1:]) and len(names) >= 2, names
 
 
 @pytest.mark.parametrize("p,rhs", [(5, "lorenz63"), (6, "lorenz63"), (6, "higher_order"), (8, "higher_order")])
@@ -112,11 +112,11 @@ def test_blocked_tiles_other_block_counts(ra, p, rhs):
         _close(m, mo, v, vo, p)
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 9, 10, 16, 17, 25])
-@pytest.mark.parametrize("B", [1, 3])
-def test_blocked_tiles_short_horizons_and_ragged_batches(ra, N, B):
-    """Around the backward chunk size (8 steps, 3 in flight) and with unit counts that do not fill a wave."""
-    p = 5
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 9, 10, 16, 17, 25, 26, 33])
+@pytest.mark.parametrize("B,p", [(1, 5), (3, 5), (3, 6), (2, 7)])
+def test_blocked_tiles_short_horizons_and_ragged_batches(ra, N, B, p):
+    """Around the backward chunk sizes (8-step chunks / rings, three producer stages in flight) and with unit counts that
+    do not fill a wave."""
     s = _fitz(ra, p, B=B, seed=N, N=N, t_max=0.01 * N)
     args = (s["W"], s["x0"], 0.0, s["t_max"], N)
     m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
