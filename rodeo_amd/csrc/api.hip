@@ -50,7 +50,7 @@ using namespace rk;
 extern "C" {
 
 const char* rk_last_error(void) { return g_err; }
-const char* rk_version(void) { return "rodeo_kalman 0.1.0 (gfx950)"; }
+const char* rk_version(void) { return "rodeo_kalman 0.2.0 (gfx950)"; }
 
 int rk_device_count(int* n) {
     RK_REQUIRE(n, RK_ERR_INVALID, "rk_device_count: null pointer");
@@ -58,6 +58,24 @@ int rk_device_count(int* n) {
     if (e != hipSuccess) { *n = 0; return hip_fail(e, "hipGetDeviceCount", __FILE__, __LINE__); }
     return RK_OK;
 }
+
+}  // extern "C"  (closed for the primer kernel, reopened below)
+
+namespace rk {
+// Placement primer.  The forward filter kernels are one dependent chain per wave: their run time is the time of the
+// SLOWEST wave, and two waves on one SIMD take 1.84x as long as one.  Behind a kernel of another workgroup shape (the
+// backward kernels: 256 threads, 48 KB of LDS) the hardware dispatcher does not spread 1024 single-wave workgroups over
+// the 1024 SIMDs: measured per-wave HW_ID (scripts/placement_probe.py, profiles/r02_placement_probe.jsonl) -- 45 to 75
+// SIMDs get two waves and as many stay empty, 0.46 -> 0.76 ms at 2048 trajectories; behind a kernel of its OWN shape the
+// placement is exact.  An empty launch of that shape in front (2-3 us) restores it: 0.455 ms, 1024 distinct SIMDs.
+__global__ void placement_primer_kernel() {}
+
+void launch_placement_primer(rk_handle h, dim3 grid, dim3 block) {
+    if (grid.x >= 256) hipLaunchKernelGGL(placement_primer_kernel, grid, block, 0, h->stream);
+}
+}  // namespace rk
+
+extern "C" {
 
 int rk_create(int device_id, rk_handle* out) {
     RK_REQUIRE(out, RK_ERR_INVALID, "rk_create: null handle pointer");

@@ -54,4 +54,7 @@ struct LaunchTimer {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// An empty kernel with the grid / block shape of the latency-bound forward kernel that follows it (api.hip).
+void launch_placement_primer(rk_handle h, dim3 grid, dim3 block);
+
 }  // namespace rk

@@ -575,6 +575,7 @@ template <class RHS>
 static int launch_fwd_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles) {
     const dim3 grid(div_up(a.B * RHS::D, Tpw<RHS::D>::value)), block(64);
     LaunchTimer t(h, "fwd_tile3_kernel");
+    launch_placement_primer(h, grid, block);           // (common.hpp: exact one-wave-per-SIMD placement behind any kernel)
     switch (c->interrogate) {
         case RK_INTERROGATE_KRAMER:
             hipLaunchKernelGGL((fwd_tile3_kernel<RHS, RK_INTERROGATE_KRAMER>), grid, block, 0, h->stream, a, tiles); break;

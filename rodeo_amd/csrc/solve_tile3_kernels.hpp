@@ -158,6 +158,14 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             store_row(M);
         }
 #undef RK_AFTER
+#ifdef RK_PLACEMENT_DEBUG
+        // experiment build only (scripts/placement_probe.py): where this wave ran, into its slice of the scratch tail
+        if (lane == 0) {
+            double* tail = tiles + (size_t)(a.N + 1) * tstride_all + (size_t)blockIdx.x * 64;
+            tail[0] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+            tail[1] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+        }
+#endif
         return;
     }
     if constexpr (rhs_has_tile_form<RHS>::value && D == 2 && ITG == RK_INTERROGATE_CHKREBTII) {
