@@ -273,6 +273,161 @@ bwd_mv_tilen_kernel(SolveArgs a, double* __restrict__ tiles, const double* __res
         if (s < n - n_bot + 1) step(n - s, q[s]);         // (uniform condition)
 }
 
+// ---- solve_mv chain with coalesced rows (template over n_bstate) --------------------------------------------------------
+// The chain above issues 22 scattered 8-byte memory instructions per step (16 loads, 6 stores: every lane its own tile
+// element); each costs the address path ~40 cycles whatever the data volume, and together they -- not the 20 MFMAs --
+// set its step time (measured: without the stores 1.36 instead of 1.80 ms at n_bstate = 5).  Used at n_bstate = 7, 8 (see
+// tilen_solve for the measured crossover).  The four units of a wave are
+// contiguous in the workspace row (4 RS doubles) and in the tile row (4 (p^2 + p) doubles), so this version moves whole
+// rows: 16-byte-per-lane raw buffer loads into registers TS_LA steps ahead, ds_write_b128 into a per-wave LDS slot, the tile
+// elements out of LDS in the D layout (padding lanes read a zero word), and the smoothed tiles back through LDS as one
+// coalesced 16-byte-per-lane store.  Same arithmetic in the same order as bwd_mv_tilen_kernel.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int TS_LA = 4;                                   // steps of row loads in flight
+
+template <int P>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+bwd_mv_tilen_rows_kernel(SolveArgs a, double* __restrict__ tiles, const double* __restrict__ ws, int n_top, int n_bot) {
+    constexpr int NB = P <= 4 ? 1 : 2, PP = P * P + P, RS0 = 2 * P * P + P, RS = RS0 + (RS0 & 1);
+    constexpr int WB = 4 * RS * 8, TB = 4 * PP * 8;                         // bytes of the wave's workspace / tile row part
+    constexpr int NLW = (WB + 1023) / 1024, NLT = (TB + 1023) / 1024;       // 16-byte-per-lane instructions per part
+    constexpr int SLOT = (NLW + NLT) * 128;                                 // doubles per staging slot (whole instructions)
+    constexpr int TOFF = NLW * 128;                                         // tile part inside a slot
+    __shared__ __attribute__((aligned(16))) double lds[2 * SLOT + NLT * 128 + 2];
+    double* const outz = lds + 2 * SLOT;                                    // output staging (NLT * 128 doubles)
+    constexpr int ZERO = 2 * SLOT + NLT * 128, DUMP = ZERO + 1;             // a zero word for padding lanes; a dump word
+    const int n_units = a.B * a.D;
+    const int lane = threadIdx.x, r = lane >> 4, g = (lane >> 2) & 3, c = lane & 3;
+    const int n_valid = n_units - (int)blockIdx.x * 4 < 4 ? n_units - (int)blockIdx.x * 4 : 4;
+    const bool valid = g < n_valid;
+    if (lane == 0) { lds[ZERO] = 0.0; lds[DUMP] = 0.0; }
+    // LDS offsets (doubles, relative to a slot / to the output staging) of this lane's tile elements
+    int lG[NB][NB], lP[NB][NB], lS[NB][NB], lMp[NB], lMf[NB], oS[NB][NB], oM[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int i = 4 * k + r;
+        const bool iv = valid && i < P;
+        lMp[k] = iv ? g * RS + 2 * P * P + i : -1;
+        lMf[k] = iv ? TOFF + g * PP + P * P + i : -1;
+        oM[k] = (iv && c == 0) ? g * PP + P * P + i : -1;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const int j = 4 * bb + c;
+            const bool in = iv && j < P;
+            lG[k][bb] = in ? g * RS + i * P + j : -1;
+            lP[k][bb] = in ? g * RS + P * P + i * P + j : -1;
+            lS[k][bb] = in ? TOFF + g * PP + i * P + j : -1;
+            oS[k][bb] = in ? g * PP + i * P + j : -1;
+        }
+    }
+    const size_t tstride = (size_t)n_units * PP, wstride = (size_t)n_units * RS;
+    const double* const tw = tiles + (size_t)blockIdx.x * 4 * PP;
+    const double* const ww = ws + (size_t)blockIdx.x * 4 * RS;
+    const int tbytes = n_valid * PP * 8, wbytes = n_valid * RS * 8;         // rows past the last unit read as zeros
+    struct Row { u32x4 w[NLW], t[NLT]; };
+    auto gload = [&](int n, Row& q) {
+        const __amdgpu_buffer_rsrc_t rw = buf_window(ww + (size_t)n * wstride, wbytes);
+        const __amdgpu_buffer_rsrc_t rt = buf_window(tw + (size_t)n * tstride, tbytes);
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) q.w[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, 1024 * i + 16 * lane, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NLT; ++i) q.t[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, 1024 * i + 16 * lane, 0, 0);
+    };
+    auto to_lds = [&](const Row& q, int slot) {
+        u32x4* dst = (u32x4*)(lds + slot * SLOT);
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) dst[64 * i + lane] = q.w[i];
+#pragma unroll
+        for (int i = 0; i < NLT; ++i) dst[64 * (NLW + i) + lane] = q.t[i];
+    };
+    struct Rec { double Gt[NB][NB], Sp[NB][NB], Sf[NB][NB], mp[NB], mf[NB]; };
+    auto from_lds = [&](int slot, Rec& q) {
+        const double* s0 = lds + slot * SLOT;
+        auto rd = [&](int off) { return off >= 0 ? s0[off] : lds[ZERO]; };
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            q.mp[k] = rd(lMp[k]);
+            q.mf[k] = rd(lMf[k]);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                q.Gt[k][bb] = rd(lG[k][bb]);
+                q.Sp[k][bb] = rd(lP[k][bb]);
+                q.Sf[k][bb] = rd(lS[k][bb]);
+            }
+        }
+    };
+    // carry: the tile of step n_top + 1 (filt[N] for the first launch, solve.py:279-282)
+    double Ms[NB][NB], ms[NB];
+    {
+        Row q;
+        const __amdgpu_buffer_rsrc_t rt = buf_window(tw + (size_t)(n_top + 1) * tstride, tbytes);
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) q.w[i] = u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NLT; ++i) q.t[i] = __builtin_amdgcn_raw_buffer_load_b128(rt, 1024 * i + 16 * lane, 0, 0);
+        to_lds(q, 0);
+        Rec c0;
+        from_lds(0, c0);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            ms[k] = c0.mf[k];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) Ms[k][bb] = c0.Sf[k][bb];
+        }
+    }
+    auto step = [&](int n, const Rec& q) {
+        double Dm[NB][NB], dm[NB], V1[NB][NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            dm[k] = ms[k] - q.mp[k];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) Dm[k][bb] = Ms[k][bb] - q.Sp[k][bb];
+        }
+        bmm_tn0<NB>(Dm, q.Gt, V1);                       // (G D)^T
+        bmm_tn<NB>(V1, q.Gt, q.Sf, Ms);                  // G D G^T + Sigma_f      (standard.py:215-216)
+        bmv_t<NB>(q.Gt, dm, q.mf, ms);                   // G (m_s - m-) + mu_f    (standard.py:213-214)
+        // the smoothed tiles back as whole rows: D layout -> LDS -> 16 bytes per lane
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            outz[oM[k] >= 0 ? oM[k] : DUMP - 2 * SLOT] = ms[k];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) outz[oS[k][bb] >= 0 ? oS[k][bb] : DUMP - 2 * SLOT] = Ms[k][bb];
+        }
+        const __amdgpu_buffer_rsrc_t rt = buf_window(tw + (size_t)n * tstride, tbytes);
+        const u32x4* src = (const u32x4*)outz;
+#pragma unroll
+        for (int i = 0; i < NLT; ++i) __builtin_amdgcn_raw_buffer_store_b128(src[64 * i + lane], rt, 1024 * i + 16 * lane, 0, 0);
+    };
+    // rows of the next TS_LA steps in registers; the record of the next step already in LDS / in `nxt` while the current
+    // one is consumed (indices below n_bot are clamped: a harmless reload that is never consumed)
+    Row rows[TS_LA];
+    int n = n_top;
+#pragma unroll
+    for (int s = 0; s < TS_LA; ++s) gload(n - s >= n_bot ? n - s : n_bot, rows[s]);
+    Rec cur, nxt;
+    to_lds(rows[0], 1);
+    from_lds(1, cur);
+    { const int nn = n - TS_LA; gload(nn >= n_bot ? nn : n_bot, rows[0]); }
+    int parity = 0;                                       // the slot the NEXT record goes to
+    while (n >= n_bot) {
+#pragma unroll
+        for (int s = 0; s < TS_LA; ++s) {
+            if (n - s >= n_bot) {                         // (uniform)
+                // stage the record of step n - s - 1 (rows[(s + 1) % TS_LA]) and refill that register slot
+                constexpr int dummy = 0; (void)dummy;
+                const int s1 = (s + 1) % TS_LA;
+                to_lds(rows[s1], parity);
+                from_lds(parity, nxt);
+                { const int nn = n - s - 1 - TS_LA; gload(nn >= n_bot ? nn : n_bot, rows[s1]); }
+                parity ^= 1;
+                step(n - s, cur);
+                cur = nxt;
+            }
+        }
+        n -= TS_LA;
+    }
+}
+
 template <int NB>
 __global__ void __launch_bounds__(64) bwd_sim_tilen_kernel(SolveArgs a, const double* __restrict__ tiles, const double* __restrict__ ws, int P) {
     const int D = a.D, n_units = a.B * D, PP = P * P + P, RS = tilen_rs(P, true);
@@ -453,9 +608,20 @@ int tilen_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     }
     if (a.N < 2) return RK_OK;
     const int steps = a.N - 1;
+    // measured (FN headline shape, ms): element-per-lane chain 1.80 / 2.33 / 3.41 / 4.09 at n_bstate = 5 / 6 / 7 / 8, coalesced
+    // rows through LDS 2.07 / 2.30 / 2.82 / 3.72 -- the LDS traffic of the staging costs what the address path saves until the
+    // tiles are nearly full; RK_TILEN_CHAIN = rows | scattered overrides the choice
+    static const char* const force = getenv("RK_TILEN_CHAIN");
+    const bool scattered = force ? force[0] == 's' : P <= 6;
     auto launch_chain = [&](int n_top, int n_bot) -> int {
-        if (tilen_nb(P) == 1) hipLaunchKernelGGL((bwd_mv_tilen_kernel<1>), cgrid, cblock, 0, h->stream, a, tiles, ws, P, n_top, n_bot);
-        else hipLaunchKernelGGL((bwd_mv_tilen_kernel<2>), cgrid, cblock, 0, h->stream, a, tiles, ws, P, n_top, n_bot);
+        if (scattered) {
+            if (tilen_nb(P) == 1) hipLaunchKernelGGL((bwd_mv_tilen_kernel<1>), cgrid, cblock, 0, h->stream, a, tiles, ws, P, n_top, n_bot);
+            else hipLaunchKernelGGL((bwd_mv_tilen_kernel<2>), cgrid, cblock, 0, h->stream, a, tiles, ws, P, n_top, n_bot);
+        } else {
+#define RK_ROWS(P_) case P_: hipLaunchKernelGGL((bwd_mv_tilen_rows_kernel<P_>), cgrid, cblock, 0, h->stream, a, tiles, ws, n_top, n_bot); break;
+            switch (P) { RK_ROWS(4) RK_ROWS(5) RK_ROWS(6) RK_ROWS(7) RK_ROWS(8) }
+#undef RK_ROWS
+        }
         RK_HIP(hipGetLastError());
         return RK_OK;
     };

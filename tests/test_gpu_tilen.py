@@ -89,6 +89,31 @@ def test_blocked_tiles_kernels_are_the_ones_that_run(ra, p):
     assert names[0] == "fwd_tilen_kernel" and all("tilen" in k for k in names[1:]) and len(names) >= 2, names
 
 
+def test_blocked_tiles_chain_variants_agree(ra):
+    """The two forms of the solve_mv chain (element-per-lane accesses; whole rows through LDS) are the same arithmetic:
+    bit-identical results at every n_bstate (the library picks one per size; RK_TILEN_CHAIN forces it -- read once per
+    process, so this test runs the other form in a child process)."""
+    import subprocess, sys, os, json
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r); import rodeo_amd as ra\n"
+        "out = {}\n"
+        "for p in (4, 5, 6, 7, 8):\n"
+        "    import functools\n"
+        "    theta = np.array([0.2, 0.2, 3.0]); W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)\n"
+        "    x0 = init(np.array([[-1., 1.], [-0.9, 1.1], [-1.1, 0.9]]), 0.0, theta=theta)\n"
+        "    g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type='standard') if p == 4 else ra.interrogate.interrogate_kramer\n"
+        "    m, v = ra.solve_mv(3, ra.ode.fitzhugh_nagumo, W, x0, 0.0, 0.5, 37, g, ra.ibm_init(0.5 / 37, p, np.array([.1, .1])), theta=theta)\n"
+        "    out[str(p)] = [float(np.sum(m)), float(np.sum(np.abs(v))), float(m[1, 20, 1, 2])]\n"
+        "print(json.dumps(out))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for form in ("rows", "scattered"):
+        env = dict(os.environ, RK_TILEN_CHAIN=form)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[form] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["rows"] == res["scattered"], res
+
+
 @pytest.mark.parametrize("p,rhs", [(5, "lorenz63"), (6, "lorenz63"), (6, "higher_order"), (8, "higher_order")])
 def test_blocked_tiles_other_block_counts(ra, p, rhs):
     """n_block = 3 (one trajectory per wave, three units) and n_block = 1 (four trajectories per wave)."""
