@@ -185,7 +185,7 @@ int user_rhs_check(const rk_solve_cfg* c) {
     RK_REQUIRE(c->n_block == g_rhs[idx].n_block && c->n_bmeas == g_rhs[idx].n_bmeas, RK_ERR_UNSUPPORTED,
                "user rhs %d needs n_block=%d, n_bmeas=%d (got %d, %d)", c->rhs_id, g_rhs[idx].n_block, g_rhs[idx].n_bmeas,
                c->n_block, c->n_bmeas);
-    const int pmax = c->n_bmeas > 1 ? 9 : 5;                     // (the backward kernels exist up to n_bstate = 9)
+    const int pmax = c->n_bmeas > 1 ? 9 : 6;                     // (the backward kernels exist up to n_bstate = 9)
     RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= pmax, RK_ERR_UNSUPPORTED, "lane-per-trajectory path supports n_bstate in [2, %d] "
                "here, got %d", pmax, c->n_bstate);
     RK_REQUIRE(c->n_bmeas <= c->n_bstate, RK_ERR_INVALID, "n_bmeas = %d exceeds n_bstate = %d", c->n_bmeas, c->n_bstate);

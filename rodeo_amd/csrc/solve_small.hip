@@ -502,8 +502,10 @@ static int launch_fwd_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a
         case 3: return launch_fwd_p<RHS, 3>(h, a, c->interrogate, sp);
         case 4: return launch_fwd_p<RHS, 4>(h, a, c->interrogate, sp);
         case 5: return launch_fwd_p<RHS, 5>(h, a, c->interrogate, sp);
+        case 6: return launch_fwd_p<RHS, 6>(h, a, c->interrogate, sp);
     }
-    set_error("small-block path supports n_bstate in [2, 5], got %d", c->n_bstate);
+    set_error("lane-per-trajectory path supports n_bstate in [2, 6] (the blocked tile path 4 .. 8 without RK_FLAG_STORE_PRED / "
+              "RK_FLAG_BATCH_MINOR), got %d", c->n_bstate);
     return RK_ERR_UNSUPPORTED;
 }
 
@@ -560,9 +562,9 @@ static int launch_itg_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a
         }                                                                               \
         break;
     switch (c->n_bstate) {
-        RK_ITG(2) RK_ITG(3) RK_ITG(4) RK_ITG(5)
+        RK_ITG(2) RK_ITG(3) RK_ITG(4) RK_ITG(5) RK_ITG(6)
         default:
-            set_error("small-block path supports n_bstate in [2, 5], got %d", c->n_bstate);
+            set_error("rk_interrogate_batched supports n_bstate in [2, 6], got %d", c->n_bstate);
             return RK_ERR_UNSUPPORTED;
     }
 #undef RK_ITG

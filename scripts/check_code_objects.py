@@ -25,7 +25,8 @@ LLVM = os.environ.get("RK_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 SCRATCH_LIMIT = 2048
 SCRATCH_ALLOW = {"kalman_op_kernel": 32768,        # kalman_batched.hip: runtime (n_state <= 16) local matrices, unit-parity ops
                  "13bwd_mv_kernel": 6144,          # solve_small.hip, one lane per (trajectory, block): the p x p register matrices
-                 "14bwd_sim_kernel": 6144}         # spill from n_bstate = 7 on (the n_bmeas > 1 / non-block path, p <= 9)
+                 "14bwd_sim_kernel": 6144,         # spill from n_bstate = 7 on (the n_bmeas > 1 / non-block path, p <= 9)
+                 "10fwd_kernelINS_8Lorenz63ELi6": 4096}   # lane-per-trajectory forward, three blocks of 6 x 6 per lane (fenrir / _solve_filter at p = 6)
 LDS_LIMIT = 160 * 1024
 FIELDS = ("agpr_count", "group_segment_fixed_size", "max_flat_workgroup_size", "private_segment_fixed_size",
           "sgpr_spill_count", "uses_dynamic_stack", "vgpr_count", "vgpr_spill_count")

@@ -241,7 +241,7 @@ def test_config4_full_size_per_gpu(ra):
         np.testing.assert_array_equal(p1.x_host()[0], x[b])
 
 
-@pytest.mark.parametrize("p", [3, 4])
+@pytest.mark.parametrize("p", [3, 4, 5, 6])
 def test_fenrir_long_horizon_sparse_observations(ra, p):
     """Fenrir with few observations on a long grid: at n_bstate = 3 the MFMA-tile kernels (forward tiles, backward filter
     with whole 16-step chunks between observations); at n_bstate = 4 the lane-per-trajectory kernels with stored
@@ -262,7 +262,7 @@ def test_fenrir_long_horizon_sparse_observations(ra, p):
                               Dw, Om, theta=theta)
     ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
     assert val.shape == (B,)
-    np.testing.assert_allclose(val, ref, rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(val, ref, rtol=1e-7 if p <= 4 else 1e-5, atol=1e-7 if p <= 4 else 1e-5)   # (conditioning, test_gpu_tilen.py)
 
 
 @pytest.mark.parametrize("N", [1, 2, 16, 17, 18, 33])
