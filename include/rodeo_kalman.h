@@ -103,7 +103,9 @@ int         rk_sync(rk_handle h);
 int         rk_timer_start(rk_handle h);
 int         rk_timer_stop(rk_handle h, double* elapsed_ms);     /* records, synchronises, returns elapsed   */
 /* Per-kernel device time of the last rk_solve_* call on this handle, from HIP events bracketing each launch.
- * Enabled with rk_profile_enable(h, 1); names/ms arrays of capacity cap are filled, *n = number of launches. */
+ * Enabled with rk_profile_enable(h, 1); names/ms arrays of capacity cap are filled, *n = number of launches.
+ * rk_profile_enable(h, 2) keeps the entries of every call since it was enabled (rk_profile_last then returns all of
+ * them, in launch order) instead of only those of the last solve; rk_profile_enable(h, 0) switches it off. */
 int         rk_profile_enable(rk_handle h, int on);
 int         rk_profile_last(rk_handle h, int cap, const char** names, double* ms, int* n);
 

@@ -87,6 +87,7 @@ int rk_create(int device_id, rk_handle* out) {
     rk_handle h = new rk_handle_s();
     h->device = device_id;
     h->profile = false;
+    h->profile_keep = false;
     h->event_used = 0;
     h->comm = nullptr;
     h->rank = 0;
@@ -191,6 +192,9 @@ int rk_timer_stop(rk_handle h, double* ms) {
 int rk_profile_enable(rk_handle h, int on) {
     RK_REQUIRE(h, RK_ERR_INVALID, "rk_profile_enable: null handle");
     h->profile = on != 0;
+    h->profile_keep = on == 2;
+    h->prof.clear();
+    h->event_used = 0;
     return RK_OK;
 }
 

@@ -16,6 +16,7 @@ struct rk_handle_s {
     hipStream_t stream;
     hipEvent_t t0, t1;
     bool profile;
+    bool profile_keep;                        // rk_profile_enable(h, 2): entries accumulate over calls
     std::vector<rk_profile_entry> prof;       // launches of the last rk_solve_* call
     std::vector<hipEvent_t> event_pool;       // reused events
     size_t event_used;

@@ -149,8 +149,8 @@ int user_forward_tile(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, do
     const int tpw = c->n_block == 3 ? 3 : 4;
     const int nw = c->n_block <= 4 ? 1 : (c->n_block + 3) / 4;     // waves per workgroup (TileWaves<D>)
     const int grid = nw == 1 ? div_up(a.B * c->n_block, tpw) : a.B;
-    LaunchTimer t(h, which == 3 ? "fwd_tile3_kernel<user>" : (which == 4 ? "fwd_tile4_kernel<user>" : "fwd_tilen_kernel<user>"));
     launch_placement_primer(h, dim3(grid), dim3(64 * nw));
+    LaunchTimer t(h, which == 3 ? "fwd_tile3_kernel<user>" : (which == 4 ? "fwd_tile4_kernel<user>" : "fwd_tilen_kernel<user>"));
     RK_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, 64 * nw, 1, 1, 0, h->stream, params, nullptr));
     t.stop();
     return RK_OK;

@@ -676,8 +676,7 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
         rc = dense_check(c, in, mode);
         if (rc) return rc;
         RK_HIP(hipSetDevice(h->device));
-        h->prof.clear();
-        h->event_used = 0;
+        if (!h->profile_keep) { h->prof.clear(); h->event_used = 0; }
         return dense_solve(h, c, in, out, mode);
     }
     RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED) || (out->mean_pred && out->var_pred), RK_ERR_INVALID,
@@ -686,8 +685,7 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD || !(c->flags & RK_FLAG_STORE_PRED), RK_ERR_UNSUPPORTED,
                "RK_FLAG_STORE_PRED is not available with kalman_type=square-root");
     RK_HIP(hipSetDevice(h->device));
-    h->prof.clear();
-    h->event_used = 0;
+    if (!h->profile_keep) { h->prof.clear(); h->event_used = 0; }
     SolveArgs a;
     make_args(c, in, out, a);
     if (c->kalman_type == RK_KALMAN_SQRT) return sqrt_solve(h, c, a, mode);

@@ -19,6 +19,8 @@
 
 namespace rk {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 // Same structure as bwd_mv_tile3_kernel (read its comments first): 4-wave workgroups, wave 0 consumes the 16-step
 // chunks, waves 1..3 produce them in three pipeline stages; LDS-DMA prefetch of the filtered tiles, hand-off through
 // LDS with the conflict-free swizzles of mfma_tile.hpp, consumer with software-pipelined LDS reads and buffer stores.
@@ -36,15 +38,26 @@ __device__ __forceinline__ int lds4_vec(int s, int g, int which, int rr) {
     return (s * TPW + g) * ITEM4 + 384 + (vec_slot(s, g, which, rr) << 3);
 }
 
+#ifdef RK_T4_STAMPS   // experiment build: per-workgroup cycle sums (consumer work / barrier wait, producer stages / wait)
+#define T4_STAMP_ARG , long long* __restrict__ dbg
+#define T4_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define T4_STAMP_ARG
+#endif
 template <int D>
-__global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* __restrict__ tiles) {
-    constexpr int P = 4, TPW = Tpw<D>::value;
+__global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, double* __restrict__ tiles T4_STAMP_ARG) {
+    constexpr int P = 4, P4 = 4, TPW = Tpw<D>::value;
     constexpr int BUF = CH4 * TPW * ITEM4;                         // 24 / 32 KiB
     constexpr int ROW_BYTES = TPW * T4_DOUBLES * 8;                // this tile-wave's bytes per time row: 480 / 640
     constexpr int N_DMA = (CH4 * ROW_BYTES / 16 + 63) / 64;        // 1-KiB LDS-DMA pieces per chunk: 8 / 10
     constexpr int ZONE = N_DMA * 1024;
     __shared__ __attribute__((aligned(16))) char lds_all[2 * BUF];
     __shared__ __attribute__((aligned(16))) char zones[3 * ZONE];
+    // Q | R of this workgroup's TPW blocks: 64 registers per producer lane if they were kept across ticks, which is
+    // what pushed the kernel over 256 registers = one workgroup per CU (the stride keeps the four blocks' rows in
+    // different banks; lanes of one block read the same address)
+    constexpr int QR_STRIDE = 2 * P4 * P4 + 2;
+    __shared__ __attribute__((aligned(16))) double qr[4 * QR_STRIDE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;    // 0 = consumer; producers q = wave - 1 own ch = q (mod 3)
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * T4_DOUBLES;
@@ -61,8 +74,17 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
         int tau = tw * TPW + (active ? g : 0);
         if (tau >= n_tiles) tau = n_tiles - 1;
         const int b = tau / D, blk = tau - b * D;
-        double Q[P][P], R[P][P];
-        load_block_consts<P>(a, blk, b, Q, R);
+        const bool buffer_ok = (CH4 - 1) * row_bytes + ROW_BYTES < 0x7fffffffull;
+        const int chunk_span = (int)((CH4 - 1) * row_bytes + ROW_BYTES);
+        if (p == 0 && s == 0) {
+            double Q0[P][P], R0[P][P];
+            load_block_consts<P>(a, blk, b, Q0, R0);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int j = 0; j < P; ++j) { qr[g * QR_STRIDE + i * P + j] = Q0[i][j]; qr[g * QR_STRIDE + P * P + i * P + j] = R0[i][j]; }
+        }
+        __syncthreads();                                           // (the consumer's matching barrier is its first one)
         int woff[16], voff[4], voff1[4];
 #pragma unroll
         for (int i = 0; i < 16; ++i) woff[i] = lds4_tile<TPW>(s, g, 0, i);
@@ -87,10 +109,18 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
             }
         };
         lds_dma_wait_all();                                        // retire the loads of Q, R before the first DMA
+        const double* const my_qr = qr + g * QR_STRIDE;
         if (p < n_chunks) fetch(p);
         double mf[P], Sf[P][P], mp[P], Sp[P][P], A[P][P], X[P][P], rpiv[P];
+#if RK_T4_STAMPS >= 2
+        long long acc[4] = {0, 0, 0, 0};
+#endif
         for (int t = -3; t < n_chunks; ++t) {
             const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
+#if RK_T4_STAMPS >= 2
+            const long long tA = T4_NOW();
+            const int stg = ch1 % 3 == p ? 0 : ((ch2 >= 0 && ch2 % 3 == p) ? 1 : 2);
+#endif
             if (ch1 % 3 == p) {
                 // ---- stage 1 of chunk ch1: fetched tiles, next fetch, predict, T^T ----
                 if (ch1 < n_chunks) {
@@ -110,8 +140,15 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
                         for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
                         mf[i] = buf[16 + i];
                     }
-                    predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
                     double T[P][P];
+                    double Q[P][P], R[P][P];
+#pragma unroll
+                    for (int k = 0; k < P * P / 2; ++k) {
+                        const double2 q2 = *(const double2*)(my_qr + 2 * k), r2 = *(const double2*)(my_qr + P * P + 2 * k);
+                        Q[(2 * k) / P][(2 * k) % P] = q2.x; Q[(2 * k + 1) / P][(2 * k + 1) % P] = q2.y;
+                        R[(2 * k) / P][(2 * k) % P] = r2.x; R[(2 * k + 1) / P][(2 * k + 1) % P] = r2.y;
+                    }
+                    predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
                     mm_nt<P, P, P>(Sf, Q, T);                        // T = Sigma_f Q^T          (standard.py:175)
 #pragma unroll
                     for (int i = 0; i < P; ++i)
@@ -131,6 +168,25 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
                 // ---- stage 3 of chunk ch3: back substitution, X = G^T (standard.py:176), hand-off ----
                 if (ch3 < n_chunks) {
                     lu_back<P, P>(A, X, rpiv);
+                    // the smoothed rows of chunk ch3 - 2: the consumer built their image in the buffer this wave is
+                    // about to refill (LDS operations of one wave execute in order); 16 bytes per lane, whole rows
+                    if (ch3 >= 2 && buffer_ok) {
+                        const char* img = lds_all + (ch3 & 1) * BUF;
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                            (void*)(wave_rows + (size_t)(a.N - 1 - (ch3 - 2) * CH4 - (CH4 - 1)) * row_bytes), 0, chunk_span, 0x00020000);
+#pragma unroll
+                        for (int i0 = 0; i0 < N_DMA; i0 += 4) {
+                            u32x4 v[4];
+#pragma unroll
+                            for (int i = i0; i < i0 + 4 && i < N_DMA; ++i) v[i - i0] = *(const u32x4*)(img + frow[i] * (TPW * ITEM4) + fcol[i]);
+#pragma unroll
+                            for (int i = i0; i < i0 + 4 && i < N_DMA; ++i) {
+                                const int vo = tw * TPW + fcol[i] / (T4_DOUBLES * 8) < n_tiles
+                                                   ? (CH4 - 1 - frow[i]) * (int)row_bytes + fcol[i] : (int)0x80000000;
+                                __builtin_amdgcn_raw_buffer_store_b128(v[i - i0], rs, vo, 0, 0);
+                            }
+                        }
+                    }
                     const int n = a.N - 1 - ch3 * CH4 - s;
                     if (n >= 1 && active) {
                         char* o = lds_all + (ch3 & 1) * BUF;
@@ -148,8 +204,18 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
                     }
                 }
             }
+#if RK_T4_STAMPS >= 2
+            const long long tB = T4_NOW();
             __syncthreads();
+            const long long tC = T4_NOW();
+            acc[stg] += tB - tA; acc[3] += tC - tB;
+#else
+            __syncthreads();
+#endif
         }
+#if RK_T4_STAMPS >= 2
+        if (lane == 0) for (int k = 0; k < 4; ++k) dbg[blockIdx.x * 20 + 4 + p * 4 + k] = acc[k];
+#endif
     } else {
         // ---------------- consumer ----------------
         const T4Coord tc = t4_coord<D>(tw, lane, n_tiles);
@@ -160,10 +226,16 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
         // carry = filt[N]  (solve.py:279-282); the mean in row form
         double Ss = tc.valid ? tiles[(size_t)a.N * tstride + (size_t)tc.tau * T4_DOUBLES + idx] : 0.0;
         double ms = tc.valid ? tiles[(size_t)a.N * tstride + (size_t)tc.tau * T4_DOUBLES + 16 + r] : 0.0;
-        const int voS = tc.valid ? (int)((g * T4_DOUBLES + idx) * sizeof(double)) : (int)0x80000000;
-        const int voM = st_m ? (int)((g * T4_DOUBLES + 16 + r) * sizeof(double)) : (int)0x80000000;
         const bool buffer_ok = (CH4 - 1) * row_bytes + ROW_BYTES < 0x7fffffffull;
         const int chunk_span = (int)((CH4 - 1) * row_bytes + ROW_BYTES);
+        // row images for the 16-byte stores: lane = piece fj of row fr of a group of RPF rows (10 pieces per tile)
+        constexpr int PIECES = ROW_BYTES / 16, RPF = 64 / PIECES, NFL = CH4 / RPF;
+        static_assert(CH4 % RPF == 0 && ROW_BYTES <= TPW * ITEM4, "row images live inside the step's items");
+        const int fj = lane % PIECES, fr = lane / PIECES;
+        const bool fvalid = fr < RPF && tw * TPW + fj / 10 < n_tiles;
+        const int f_lds = fvalid ? fr * TPW * ITEM4 + fj * 16 : 0;
+        const int f_vo = fvalid && buffer_ok ? (int)((RPF - 1 - fr) * row_bytes) + fj * 16 : (int)0x80000000;
+        const int wS = gl * (T4_DOUBLES * 8) + idx * 8, wM = gl * (T4_DOUBLES * 8) + 128 + r * 8;
         int roff[4], rvec[4], rvec1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -171,16 +243,31 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
             rvec[k] = lds4_vec<TPW>(k, gl, 0, r) - k * TPW * ITEM4;
             rvec1[k] = lds4_vec<TPW>(k, gl, 1, r) - k * TPW * ITEM4;
         }
+        __syncthreads();                                            // Q | R of the blocks are in LDS
         __syncthreads();                                            // tick -3
         __syncthreads();                                            // tick -2
         __syncthreads();                                            // tick -1: chunk 0 is in LDS
+#ifdef RK_T4_STAMPS
+        long long cacc[2] = {0, 0};
+        const long long rt0 = __builtin_amdgcn_s_memrealtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#endif
         for (int t = 0; t < n_chunks; ++t) {
+#ifdef RK_T4_STAMPS
+            const long long tA = T4_NOW();
+#endif
             const char* in = lds_all + (t & 1) * BUF;
             const int n_hi = a.N - 1 - t * CH4;
             const int cnt = __builtin_amdgcn_readfirstlane(n_hi >= CH4 ? CH4 : n_hi);
             if (cnt == CH4 && buffer_ok) {
-                // branch-free chunk: LDS reads LOOKAHEAD steps ahead (five per step, lgkmcnt holds 15), three MFMAs,
-                // two subtractions and two buffer stores per step
+                // branch-free chunk: LDS reads LOOKAHEAD steps ahead (five per step), three MFMAs and two subtractions
+                // per step.  The results do not go to memory lane by lane (an 8-byte-per-lane store occupies the CU's
+                // address path for ~40 cycles whatever it carries: two of them per step and two workgroups per CU
+                // were the kernel's bound): each lane drops its element into the image of the time row, built in the
+                // LDS bytes of the step's own items (read by now), and every RPF steps one 16-byte-per-lane store
+                // writes RPF whole rows.
                 constexpr int LOOKAHEAD = 2;
                 double Sp[CH4], Gt[CH4], Sf[CH4], mp[CH4], mf[CH4];
                 auto load = [&](int s) {
@@ -193,8 +280,11 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
                 };
 #pragma unroll
                 for (int s = 0; s < LOOKAHEAD; ++s) load(s);
+                char* const img = lds_all + (t & 1) * BUF;
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                     (void*)(wave_rows + (size_t)(n_hi - (CH4 - 1)) * row_bytes), 0, chunk_span, 0x00020000);
+                const bool self_flush = t + 2 >= n_chunks;          // (no producer refills this buffer any more)
+                u32x4 fl[NFL];
 #pragma unroll
                 for (int s = 0; s < CH4; ++s) {
                     if (s + LOOKAHEAD < CH4) load(s + LOOKAHEAD);
@@ -202,14 +292,17 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
                     const double V1 = MF(Ss - Sp[s], Gt[s], 0.0);       // (G D)^T
                     ms = MF(Gt[s], ms - mp[s], mf[s]);                  // mu_f + G (mu_s - mu-)     (standard.py:213-214)
                     Ss = MF(V1, Gt[s], Sf[s]);                          // Sigma_f + G D G^T         (standard.py:215-216)
-                    u32x2 bS, bM;
-                    __builtin_memcpy(&bS, &Ss, 8);
-                    __builtin_memcpy(&bM, &ms, 8);
-                    const int soff = (int)((CH4 - 1 - s) * row_bytes);
-                    __builtin_amdgcn_raw_buffer_store_b64(bS, rsrc, voS, soff, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(bM, rsrc, voM, soff, 0);
+                    if (tc.valid) *(double*)(img + s * TPW * ITEM4 + wS) = Ss;      // (exec-masked: measured faster than
+                    if (st_m) *(double*)(img + s * TPW * ITEM4 + wM) = ms;          // sending idle lanes to a dump slot)
+                    if ((s + 1) % RPF == 0 && self_flush) {
+                        const int k = s / RPF;
+                        fl[k] = *(const u32x4*)(img + (s - (RPF - 1)) * TPW * ITEM4 + f_lds);
+                        if (k >= 1)
+                            __builtin_amdgcn_raw_buffer_store_b128(fl[k - 1], rsrc, f_vo, (int)((CH4 - s + RPF - 1) * row_bytes), 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (self_flush) __builtin_amdgcn_raw_buffer_store_b128(fl[NFL - 1], rsrc, f_vo, 0, 0);
             } else {
                 for (int s = 0; s < cnt; ++s) {
                     const char* q = in + lds4_tile<TPW>(s, gl, 0, idx);
@@ -224,8 +317,18 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
                     if (st_m) row[16 + r] = ms;
                 }
             }
+#ifdef RK_T4_STAMPS
+            const long long tB = T4_NOW();
             __syncthreads();
+            const long long tC = T4_NOW();
+            cacc[0] += tB - tA; cacc[1] += tC - tB;
+#else
+            __syncthreads();
+#endif
         }
+#ifdef RK_T4_STAMPS
+        if (lane == 0) { dbg[blockIdx.x * 20] = cacc[0]; dbg[blockIdx.x * 20 + 1] = cacc[1]; dbg[blockIdx.x * 20 + 2] = n_chunks; dbg[blockIdx.x * 20 + 16] = rt0; dbg[blockIdx.x * 20 + 17] = __builtin_amdgcn_s_memrealtime(); dbg[blockIdx.x * 20 + 18] = ((long long)xcc << 32) | hwid; }
+#endif
     }
 }
 
@@ -233,8 +336,8 @@ __global__ void __launch_bounds__(256) bwd_mv_tile4_kernel(SolveArgs a, double* 
 template <class RHS>
 static int launch_fwd_tile4(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles) {
     const dim3 grid(div_up(a.B * RHS::D, Tpw<RHS::D>::value)), block(64);
-    LaunchTimer t(h, "fwd_tile4_kernel");
     launch_placement_primer(h, grid, block);           // (common.hpp: exact one-wave-per-SIMD placement behind any kernel)
+    LaunchTimer t(h, "fwd_tile4_kernel");
     switch (c->interrogate) {
         case RK_INTERROGATE_KRAMER:
             hipLaunchKernelGGL((fwd_tile4_kernel<RHS, RK_INTERROGATE_KRAMER>), grid, block, 0, h->stream, a, tiles); break;
@@ -286,12 +389,53 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     const int tpw = a.D == 3 ? 3 : 4;
     const dim3 grid(div_up(a.B * a.D, tpw)), block(256);
     LaunchTimer t(h, "bwd_mv_tile4_kernel");
-    if (a.D == 1) hipLaunchKernelGGL((bwd_mv_tile4_kernel<1>), grid, block, 0, h->stream, a, tiles);
-    else if (a.D == 2) hipLaunchKernelGGL((bwd_mv_tile4_kernel<2>), grid, block, 0, h->stream, a, tiles);
-    else if (a.D == 3) hipLaunchKernelGGL((bwd_mv_tile4_kernel<3>), grid, block, 0, h->stream, a, tiles);
-    else hipLaunchKernelGGL((bwd_mv_tile4_kernel<4>), grid, block, 0, h->stream, a, tiles);
+#ifdef RK_T4_STAMPS
+    long long* dbg = nullptr;
+    RK_HIP(hipMalloc(&dbg, (size_t)grid.x * 20 * sizeof(long long)));
+    RK_HIP(hipMemsetAsync(dbg, 0, (size_t)grid.x * 20 * sizeof(long long), h->stream));
+#define T4_DBG , dbg
+#else
+#define T4_DBG
+#endif
+    if (a.D == 1) hipLaunchKernelGGL((bwd_mv_tile4_kernel<1>), grid, block, 0, h->stream, a, tiles T4_DBG);
+    else if (a.D == 2) hipLaunchKernelGGL((bwd_mv_tile4_kernel<2>), grid, block, 0, h->stream, a, tiles T4_DBG);
+    else if (a.D == 3) hipLaunchKernelGGL((bwd_mv_tile4_kernel<3>), grid, block, 0, h->stream, a, tiles T4_DBG);
+    else hipLaunchKernelGGL((bwd_mv_tile4_kernel<4>), grid, block, 0, h->stream, a, tiles T4_DBG);
     t.stop();
     RK_HIP(hipGetLastError());
+#ifdef RK_T4_STAMPS
+    {
+        std::vector<long long> hd((size_t)grid.x * 20);
+        RK_HIP(hipMemcpyAsync(hd.data(), dbg, hd.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+        RK_HIP(hipStreamSynchronize(h->stream));
+        RK_HIP(hipFree(dbg));
+        double m[16] = {0};
+        for (unsigned w = 0; w < grid.x; ++w) for (int k = 0; k < 16; ++k) m[k] += (double)hd[w * 20 + k] / grid.x;
+        const double nc = m[2] > 0 ? m[2] : 1;
+        fprintf(stderr, "[t4 stamps] per tick (mean over %u workgroups, %g ticks): consumer work %.0f wait %.0f |", grid.x, nc, m[0] / nc, m[1] / nc);
+        for (int p = 0; p < 3; ++p) fprintf(stderr, " producer %d: stage1 %.0f stage2 %.0f stage3 %.0f wait %.0f |", p, m[4 + 4 * p] * 3 / nc, m[5 + 4 * p] * 3 / nc, m[6 + 4 * p] * 3 / nc, m[7 + 4 * p] / nc);
+        fprintf(stderr, "\n");
+        long long t_min = hd[16], t_max = hd[17]; double life = 0;
+        std::vector<int> per_cu(8 * 128, 0), simd_of(8 * 128, -1); int same_simd = 0, pairs = 0;
+        for (unsigned w = 0; w < grid.x; ++w) {
+            t_min = std::min(t_min, hd[w * 20 + 16]); t_max = std::max(t_max, hd[w * 20 + 17]);
+            life += (double)(hd[w * 20 + 17] - hd[w * 20 + 16]) / grid.x;
+            const unsigned hw = (unsigned)hd[w * 20 + 18], xc = (unsigned)(hd[w * 20 + 18] >> 32) & 7;
+            const unsigned cu = (hw >> 8) & 15, se = (hw >> 13) & 7;    // HW_ID: cu_id [11:8], sh [12], se [15:13]
+            const unsigned simd = (hw >> 4) & 3;
+            const int key = xc * 128 + se * 16 + cu;
+            if (simd_of[key] >= 0) { pairs++; same_simd += simd_of[key] == (int)simd; }
+            simd_of[key] = (int)simd;
+            per_cu[key] += 1;
+        }
+        int hist[8] = {0};
+        for (int v : per_cu) if (v < 8) hist[v]++;
+        fprintf(stderr, "[t4 stamps] kernel span %.1f us (100 MHz clock), mean workgroup lifetime %.1f us; workgroups per (xcc, se, cu): ", (t_max - t_min) / 100.0, life / 100.0);
+        for (int k = 1; k < 8; ++k) if (hist[k]) fprintf(stderr, "%d CUs with %d, ", hist[k], k);
+        fprintf(stderr, "consumer waves of a CU on the same SIMD: %d of %d pairs", same_simd, pairs);
+        fprintf(stderr, "\n");
+    }
+#endif
     return RK_OK;
 }
 

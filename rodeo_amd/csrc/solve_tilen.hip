@@ -510,8 +510,8 @@ static int launch_fwd_tilen_nb(rk_handle h, const rk_solve_cfg* c, const SolveAr
     constexpr int NW = TileWaves<RHS::D>::value;
     const dim3 grid(NW == 1 ? div_up(a.B * RHS::D, Tpw<RHS::D>::value) : a.B), block(64 * NW);
     const int P = c->n_bstate;
-    LaunchTimer t(h, "fwd_tilen_kernel");
     launch_placement_primer(h, grid, block);           // (common.hpp: exact one-wave-per-SIMD placement behind any kernel)
+    LaunchTimer t(h, "fwd_tilen_kernel");
     switch (c->interrogate) {
         case RK_INTERROGATE_KRAMER:
             hipLaunchKernelGGL((fwd_tilen_kernel<RHS, RK_INTERROGATE_KRAMER, NB>), grid, block, 0, h->stream, a, tiles, P); break;

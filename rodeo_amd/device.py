@@ -67,8 +67,9 @@ class Device:
         _lib.check(self.lib.rk_timer_stop(self.h, C.byref(ms)))
         return ms.value
 
-    def profile_enable(self, on=True):
-        _lib.check(self.lib.rk_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, on=True, keep=False):
+        """HIP events around every launch; ``keep=True`` accumulates over calls (read them all with ``profile_last(cap)``)."""
+        _lib.check(self.lib.rk_profile_enable(self.h, (2 if keep else 1) if on else 0))
 
     def profile_last(self, cap=16):
         names = (C.c_char_p * cap)()

@@ -87,6 +87,17 @@ def test_blocked_tiles_kernels_are_the_ones_that_run(ra, p):
     names = [k for k, _ in plan.dev.profile_last()]
     plan.dev.profile_enable(False)
     assert names[0] == "fwd_tilen_kernel" and all("tilen" in k for k in names[1:]) and len(names) >= 2, names
+    # keep=True: the launches of every call since it was switched on (what bench.py reads after its timed region)
+    plan.dev.profile_enable(True, keep=True)
+    for _ in range(3):
+        plan.mv(None)
+    kept = plan.dev.profile_last(cap=64)
+    plan.dev.profile_enable(False)
+    assert [k for k, _ in kept] == names * 3 and all(ms > 0 for _, ms in kept)
+    plan.dev.profile_enable(True)
+    plan.mv(None)
+    assert [k for k, _ in plan.dev.profile_last()] == names
+    plan.dev.profile_enable(False)
 
 
 def test_blocked_tiles_chain_variants_agree(ra):
