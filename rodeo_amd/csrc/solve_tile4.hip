@@ -25,8 +25,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // chunks, waves 1..3 produce them in three pipeline stages; LDS-DMA prefetch of the filtered tiles, hand-off through
 // LDS with the conflict-free swizzles of mfma_tile.hpp, consumer with software-pipelined LDS reads and buffer stores.
 // A wave carries TPW = 3 (n_block = 3: the three blocks of one trajectory) or 4 tiles; items are packed TPW to a time
-// step, so Lorenz63 (config C3) needs 48 + 24 KiB of LDS per workgroup and two workgroups share a CU.
-constexpr int CH4 = 16;                          // time steps per hand-off
+// step and the chunk is 16 (TPW = 3) or 12 (TPW = 4) steps, so a workgroup needs 48 + 24 (+ 1) KiB of LDS and at most
+// 256 registers per lane: two workgroups share a CU (measured with per-workgroup time stamps, -DRK_T4_STAMPS: with
+// 260 registers the two workgroups of a CU ran one after the other).
 constexpr int ITEM4 = 512;                       // bytes per (step, tile): S- | G^T | S_f tiles, then m- (4), m_f (4)
 
 template <int TPW>
@@ -47,7 +48,10 @@ __device__ __forceinline__ int lds4_vec(int s, int g, int which, int rr) {
 template <int D>
 __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, double* __restrict__ tiles T4_STAMP_ARG) {
     constexpr int P = 4, P4 = 4, TPW = Tpw<D>::value;
-    constexpr int BUF = CH4 * TPW * ITEM4;                         // 24 / 32 KiB
+    // time steps per hand-off: 16 with three tiles per wave, 12 with four -- 74 KiB of LDS either way, so that TWO
+    // workgroups share a CU (with 16 steps x 4 tiles: 96 KiB, one workgroup per CU, the chain waves idle half the time)
+    constexpr int CH4 = TPW == 3 ? 16 : 12;
+    constexpr int BUF = CH4 * TPW * ITEM4;                         // 24 KiB
     constexpr int ROW_BYTES = TPW * T4_DOUBLES * 8;                // this tile-wave's bytes per time row: 480 / 640
     constexpr int N_DMA = (CH4 * ROW_BYTES / 16 + 63) / 64;        // 1-KiB LDS-DMA pieces per chunk: 8 / 10
     constexpr int ZONE = N_DMA * 1024;
@@ -70,7 +74,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
         // ---------------- producers: one lane per (step-in-chunk, tile) ----------------
         const int p = wave - 1;
         const int s = lane >> 2, g = lane & 3;
-        const bool active = g < TPW;
+        const bool active = g < TPW && s < CH4;
         int tau = tw * TPW + (active ? g : 0);
         if (tau >= n_tiles) tau = n_tiles - 1;
         const int b = tau / D, blk = tau - b * D;
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
                 if (ch1 < n_chunks) {
                     lds_dma_wait_all();
                     double buf[T4_DOUBLES];
-                    const char* mine = zone + s * ROW_BYTES + (active ? g : 0) * (T4_DOUBLES * 8);
+                    const char* mine = zone + (active ? s * ROW_BYTES + g * (T4_DOUBLES * 8) : 0);
 #pragma unroll
                     for (int k = 0; k < T4_DOUBLES / 2; ++k) {
                         const double2 v = *(const double2*)(mine + 16 * k);

@@ -67,6 +67,27 @@ def demangled(name):
         return name
 
 
+# Producer/consumer kernels whose design counts on TWO workgroups per CU (the chain wave of one fills the stalls of the
+# other): a few registers too many make the two workgroups of a CU run one after the other without any other symptom
+# (found with per-workgroup time stamps on bwd_mv_tile4_kernel, which had crept to 260 registers: DESIGN.md).
+MIN_WORKGROUPS_PER_CU = {"19bwd_mv_tile3_kernel": 2, "19bwd_mv_tile4_kernel": 2, "20bwd_sim_tile3_kernel": 2,
+                         "23fenrir_bwd_tile3_kernel": 2}
+
+
+def workgroups_per_cu(k):
+    """Resident workgroups per CU allowed by registers (512 per lane and SIMD, granule 8, 8 waves per SIMD at most)
+    and by LDS (160 KiB)."""
+    wg = k.get("max_flat_workgroup_size", 1024)
+    regs = k.get("vgpr_count", 0) + k.get("agpr_count", 0)
+    alloc = max(8, -(-regs // 8) * 8)
+    waves_per_simd = min(8, 512 // alloc)
+    waves = -(-wg // 64)
+    by_regs = (waves_per_simd * 4) // waves
+    lds = k.get("group_segment_fixed_size", 0)
+    by_lds = LDS_LIMIT // lds if lds else 32
+    return min(by_regs, by_lds, 32 // waves)
+
+
 def check(kernels):
     problems = []
     for k in kernels:
@@ -78,6 +99,11 @@ def check(kernels):
             problems.append(f"{nm}: {k['private_segment_fixed_size']} B of scratch per lane (limit {lim})")
         if k.get("group_segment_fixed_size", 0) > LDS_LIMIT:
             problems.append(f"{nm}: {k['group_segment_fixed_size']} B of LDS (limit {LDS_LIMIT})")
+        for key, need in MIN_WORKGROUPS_PER_CU.items():
+            if key in k["name"] and workgroups_per_cu(k) < need:
+                problems.append(f"{nm}: {workgroups_per_cu(k)} workgroup(s) per CU (registers "
+                                f"{k.get('vgpr_count', 0) + k.get('agpr_count', 0)}, LDS {k.get('group_segment_fixed_size', 0)} B); "
+                                f"the kernel is built for {need}")
         wg = k.get("max_flat_workgroup_size", 1024)
         waves_per_simd = max(1, -(-wg // 256))
         regs = k.get("vgpr_count", 0) + k.get("agpr_count", 0)

@@ -155,3 +155,11 @@ def test_code_objects_fit_their_launch_assumptions():
     bad = [dict(base, uses_dynamic_stack=True), dict(base, private_segment_fixed_size=1 << 20),
            dict(base, vgpr_count=300, max_flat_workgroup_size=512)]
     assert len(cco.check(bad)) == 3
+    # two workgroups per CU where a kernel is built for that: 260 registers (or 96 KB of LDS) would halve it silently
+    pc = dict(base, name="_ZN2rk19bwd_mv_tile4_kernelILi3EEEvNS_9SolveArgsEPd", group_segment_fixed_size=74816, vgpr_count=256)
+    assert cco.workgroups_per_cu(pc) == 2 and cco.check([pc]) == []
+    assert cco.workgroups_per_cu(dict(pc, vgpr_count=260)) == 1 and len(cco.check([dict(pc, vgpr_count=260)])) == 1
+    assert cco.workgroups_per_cu(dict(pc, group_segment_fixed_size=96256)) == 1
+    for k in ks:
+        if any(key in k["name"] for key in cco.MIN_WORKGROUPS_PER_CU):
+            assert cco.workgroups_per_cu(k) >= 2, k["name"
