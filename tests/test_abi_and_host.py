@@ -162,4 +162,4 @@ def test_code_objects_fit_their_launch_assumptions():
     assert cco.workgroups_per_cu(dict(pc, group_segment_fixed_size=96256)) == 1
     for k in ks:
         if any(key in k["name"] for key in cco.MIN_WORKGROUPS_PER_CU):
-            assert cco.workgroups_per_cu(k) >= 2, k["name"
+            assert cco.workgroups_per_cu(k) >= 2, k["name"]
