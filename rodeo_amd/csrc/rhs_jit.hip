@@ -59,8 +59,8 @@ static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<c
     }
     const std::string expr = kernel_expr(u, P, itg, kind);
     hiprtcAddNameExpression(prog, expr.c_str());
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-falign-loops=64"};     // (Makefile: why aligned loops)
+    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);

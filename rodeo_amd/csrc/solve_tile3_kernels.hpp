@@ -111,7 +111,18 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
         __builtin_memcpy(&bits, &v, 8);
         __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, bvoff, 0, 0);
     };
-    store_row(M);
+    // The state of time n goes out one step LATE, behind the first MFMA of step n + 1: a store issued right behind the
+    // instruction that produced its data holds the wave's (in-order) issue until that result can be read by the memory
+    // path -- 22 cycles on a bare add-MFMA-MFMA chain against 8 when the value is a step old
+    // (profiles/r02_probe13_store_cost.log); on the headline kernel 0.483 -> 0.432 ms.  The empty asm makes the stored
+    // value "depend" on that MFMA, so the scheduler keeps the store behind it; no instruction or wait state is emitted
+    // (a macro, not a lambda: with a by-value copy of M hipcc's schedule of the headline step loses the whole gain).
+#define RK_STORE_BEHIND(M_, mfma_result)                              \
+    do {                                                              \
+        asm("" : "+v"(M_) : "v"(mfma_result));                        \
+        store_row(M_);                                                \
+        row += tstride_all * sizeof(double);                          \
+    } while (0)
 
     if constexpr (rhs_has_tile_form<RHS>::value && D == 2 && ITG != RK_INTERROGATE_CHKREBTII) {
         // The headline path.  A step is ONE dependent chain for its wave (seven MFMAs, thirteen VALU instructions, one
@@ -130,7 +141,7 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
 #define RK_AFTER(in, res) asm("" : "+v"(in) : "v"(res))
         for (int n = 0; n < a.N; ++n) {
             double U = MF(M, Qt, 0.0);                              // (Q~ M)^T                         (standard.py:57-59)
-            RK_AFTER(M, U);
+            RK_STORE_BEHIND(M, U);                                  // the state of time n
             double B0 = MF(Y0, M, 0.0);                             // row 0 of Q~ M in every row: mu-_0 in column 3
             RK_AFTER(U, B0);
             double MpT = MF(Qt0, U, RtT);                           // M-^T with row 3 zeroed: the offset entry of X_w must not enter Z0
@@ -154,9 +165,8 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             const double e = fma(-S, y0, 1.0);
             const double y = fma(y0, fma(e, e, e), y0);             // 1 / S (linalg_small.hpp, fast_rcp_cubic)
             M = fma(-PW, y, Mp);                                    // [Sigma- - K (W~ Sigma-) | mu- - K yhat]  (standard.py:98-102)
-            row += tstride_all * sizeof(double);
-            store_row(M);
         }
+        store_row(M);                                               // time N
 #undef RK_AFTER
 #ifdef RK_PLACEMENT_DEBUG
         // experiment build only (scripts/placement_probe.py): where this wave ran, into its slice of the scratch tail
@@ -188,6 +198,7 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             }
             const double zn = zbuf[tc.g * 16 + (n & 15)];
             const double U = MF(M, Qt, 0.0);
+            RK_STORE_BEHIND(M, U);
             const double Mp = MF(U, Qt, Rt);
             const double MpT = MF(Qt0, U, RtT);
             const double R0 = MF(E0, Mp, 0.0);              // row 0 of M- in every row: [Sigma-_00 .. | mu-_0]
@@ -201,9 +212,8 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             const double WS = fma(e3c, am, WS0);            // yhat = W mu- + a in column 3         (standard.py:93)
             const double PW = Z0 * WS;
             M = fma(-PW, fast_rcp_cubic(S), Mp);            // standard.py:98-102
-            row += tstride_all * sizeof(double);
-            store_row(M);
         }
+        store_row(M);
         return;
     }
     for (int n = 0; n < a.N; ++n) {
@@ -211,6 +221,7 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
         // (a 4x4x4 fp64 MFMA blocks this wave's issue for ~17 cycles = 4 fp64 VALU ops, and nothing overlaps it --
         //  profiles/r01_probe3_mfma_valu_serialize.log -- so the step is written with the fewest MFMAs: seven)
         const double U = MF(M, Qt, 0.0);
+        RK_STORE_BEHIND(M, U);
         double v_own;                                  // the point the ODE is evaluated at: X[b][0] of this tile's block
         if constexpr (ITG != RK_INTERROGATE_CHKREBTII) v_own = quad_bcast3(MF(Y0, M, 0.0));   // mu-_0 in all 16 lanes
         const double Mp = MF(U, Qt, Rt);
@@ -283,9 +294,9 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             S = S + S;                                              // var_meas = W Sigma- W^T (interrogate.py:110-113, 26-29)
         const double K = Z0 * fast_rcp_cubic(S);
         M = fma(-K, WS, Mp);
-        row += tstride_all * sizeof(double);
-        store_row(M);
     }
+    store_row(M);
+#undef RK_STORE_BEHIND
 }
 
 }  // namespace rk

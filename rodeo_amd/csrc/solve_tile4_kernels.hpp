@@ -73,9 +73,15 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
             __builtin_amdgcn_raw_buffer_store_b64(bS, rsrc, voS, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(bM, rsrc, voM, 0, 0);
         };
-        store_row(S, m);
+        // (the state of time n is stored one step late, behind the first MFMA of step n + 1: solve_tile3_kernels.hpp)
         for (int n = 0; n < a.N; ++n) {
             const double U = MF(S, Qt, 0.0);
+            {
+                double vS = S, vM = m;
+                asm("" : "+v"(vS), "+v"(vM) : "v"(U));
+                store_row(vS, vM);
+                row += tstride_all * sizeof(double);
+            }
             const double v_own = MF(Y0, m, 0.0);                      // (Q mu)_0 in all 16 lanes of the tile
             const double mp = MF(Qt, m, 0.0);                         // Q mu, row form
             const double SpT = MF(Qt, U, RtT);                        // exact transpose of S-: Q Sigma^T Q^T + R^T
@@ -90,19 +96,22 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
             const double K = -Z * fast_rcp_cubic(Sc);
             S = fma(K, WS, Sp);
             m = fma(K, yhat, mp);
-            row += tstride_all * sizeof(double);
-            store_row(S, m);
         }
+        store_row(S, m);
         return;
     }
     double* oS = tc.valid ? tiles + (size_t)tc.tau * T4_DOUBLES + r * 4 + c : dump + threadIdx.x;
     double* oM = st_m ? tiles + (size_t)tc.tau * T4_DOUBLES + 16 + r : dump + 64 + threadIdx.x;
     const size_t sS = tc.valid ? tstride_all : 0, sM = st_m ? tstride_all : 0;
-    oS[0] = S;
-    oM[0] = m;
-
     for (int n = 0; n < a.N; ++n) {
         const double U = MF(S, Qt, 0.0);
+        {
+            double vS = S, vM = m;
+            asm("" : "+v"(vS), "+v"(vM) : "v"(U));
+            oS[0] = vS;
+            oM[0] = vM;
+            oS += sS; oM += sM;
+        }
         const double v_own = MF(Y0, m, 0.0);                      // (Q mu)_0 in all 16 lanes of the tile
         const double mp = MF(Qt, m, 0.0);                         // Q mu, row form
         const double Sp = MF(U, Qt, Rt);                          // Q Sigma Q^T + R
@@ -147,10 +156,9 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
         const double K = Z * fast_rcp_cubic(Sc);
         S = fma(-K, WS, Sp);
         m = fma(-K, yhat, mp);
-        oS += sS; oM += sM;
-        oS[0] = S;
-        oM[0] = m;
     }
+    oS[0] = S;
+    oM[0] = m;
 }
 
 }  // namespace rk

@@ -147,9 +147,12 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
             offS[k][bb] = (valid && i < P && j < P) ? (int)((g * PP + i * P + j) * sizeof(double)) : (int)0x80000000;
         }
     }
-    auto store = [&]() {
+    // (called one step late, behind the first MFMAs of the next step -- `after` is one of their results, which the
+    // stored copies are made to "depend" on with an empty asm: solve_tile3_kernels.hpp, store_behind)
+    auto store = [&](double after) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, TPW * PP * 8, 0x00020000);
         auto put = [&](double v, int off) {
+            asm("" : "+v"(v) : "v"(after));
             u32x2 bits;
             __builtin_memcpy(&bits, &v, 8);
             __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, off, 0, 0);
@@ -161,7 +164,6 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
             for (int bb = 0; bb < NB; ++bb) put(S[k][bb], offS[k][bb]);
         }
     };
-    store();
 
     for (int n = 0; n < a.N; ++n) {
         if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
@@ -176,6 +178,8 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
 #pragma unroll
         for (int k = 0; k < NB; ++k) zero[k] = 0.0;
         bmm_tn0<NB>(S, Qt, U);
+        store(U[0][0]);                                   // the state of time n
+        row += tstride * sizeof(double);
         double v_own = bdot<NB>(Y0, m, 0.0);             // (Q mu)_0 in all 16 lanes of the unit: the evaluation point X[b][0]
         bmv_t<NB>(Qt, m, zero, mp);
         bmm_tn<NB>(U, Qt, Rt, Sp);
@@ -246,9 +250,8 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
 #pragma unroll
             for (int bb = 0; bb < NB; ++bb) S[k][bb] = fma(-K, WS[bb], Sp[k][bb]);
         }
-        row += tstride * sizeof(double);
-        store();
     }
+    store(0.0);                                           // time N
 }
 
 }  // namespace rk
