@@ -121,7 +121,9 @@ int rk_register_rhs_source(const char* type_name, const char* source, int32_t n_
 /* the same for a right-hand side with n_bmeas > 1 measurements per block (src/rodeo/solve.py:48-51: ode_weight (n_block,
  * n_bmeas, n_bstate)), e.g. the reference's "non-block" form of a small system (prior/indep_init.py, examples/solve_nb.py):
  * `type_name` then names a type with the interface of csrc/solve_small_m_kernels.hpp (rk::AutoJacM<...> around a
- * scalar-generic rhs writing out[D][M]); such right-hand sides run on the lane-per-trajectory kernels, n_bstate <= 9. */
+ * scalar-generic rhs writing out[D][M]); such right-hand sides run on the lane-per-trajectory kernels (n_bstate <= 9,
+ * n_bmeas <= 4) or, for ONE block beyond that (n_bmeas up to 256, n_bstate up to 768), on the dense MFMA path with its
+ * interrogation kernel built around them (csrc/solve_dense_itg_kernels.hpp; solve_mv / filter, kramer / schober / rodeo). */
 int rk_register_rhs_source_m(const char* type_name, const char* source, int32_t n_block, int32_t n_bmeas, int32_t n_theta,
                              int32_t* rhs_id);
 int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate);

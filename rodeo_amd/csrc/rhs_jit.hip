@@ -15,6 +15,7 @@
 #include <vector>
 #include "common.hpp"
 #include "solve_args.hpp"
+#include "solve_dense_itg_kernels.hpp"
 #include "build/embedded_sources.inc"
 
 namespace rk {
@@ -39,6 +40,7 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
     else if (kind == 7 || kind == 8)                                                                        // n_bmeas > 1
         snprintf(buf, sizeof buf, "rk::fwd_kernel_m<rk::UserRhsT, %d, %d, %s>", P, itg, kind == 8 ? "true" : "false");
     else if (kind == 6) snprintf(buf, sizeof buf, "rk::fwd_sqrt_kernel<rk::UserRhsT, %d, %d>", P, itg);   // square-root filter
+    else if (kind == 9) snprintf(buf, sizeof buf, "rk::dense_interrogate_kernel<rk::UserRhsT::Inner, %d, %d>", P, itg);   // dense path
     else if (kind == 5) snprintf(buf, sizeof buf, "rk::fwd_tilen_kernel<rk::UserRhsT, %d, %d>", itg, P); // blocked tiles, P here = NB
     else snprintf(buf, sizeof buf, "rk::fwd_kernel<rk::UserRhsT, %d, %d, %s>", P, itg, kind == 1 ? "true" : "false");
     return buf;
@@ -49,7 +51,7 @@ static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<c
     const std::string src = std::string("#include \"solve_small_kernels.hpp\"\n#include \"dual.hpp\"\n"
                                         "#include \"solve_tile3_kernels.hpp\"\n#include \"solve_tile4_kernels.hpp\"\n"
                                         "#include \"solve_tilen_kernels.hpp\"\n#include \"solve_sqrt_kernels.hpp\"\n"
-                                        "#include \"solve_small_m_kernels.hpp\"\nnamespace rk {\n") +
+                                        "#include \"solve_small_m_kernels.hpp\"\n#include \"solve_dense_itg_kernels.hpp\"\nnamespace rk {\n") +
                             u.source + "\nusing UserRhsT = " + u.type_name + ";\n}  // namespace rk\n";
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "rk_user_rhs.hip", kJitNumHeaders, kJitHeaderSources, kJitHeaderNames) !=
@@ -198,6 +200,26 @@ static int user_n_bmeas(int rhs_id) {
     return idx >= 0 && idx < (int)g_rhs.size() ? g_rhs[idx].n_bmeas : 1;
 }
 
+// ---- dense ("non-block") path: the interrogation kernel around the user's right-hand side (solve_dense_itg_kernels.hpp)
+// Taken for one block with several measurements that the lane kernels do not serve (n_bstate > 9 or n_bmeas > 4).
+bool user_dense_wanted(const rk_solve_cfg* c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int idx = c->rhs_id - RK_RHS_USER_BASE;
+    if (idx < 0 || idx >= (int)g_rhs.size()) return false;
+    const UserRhs& u = g_rhs[idx];
+    return u.n_block == 1 && c->n_block == 1 && u.n_bmeas > 1 && c->n_bmeas == u.n_bmeas && (c->n_bstate > 9 || c->n_bmeas > 4);
+}
+
+int user_dense_interrogate(rk_handle h, const rk_solve_cfg* c, const DenseItgArgs& a) {
+    hipFunction_t fn;
+    int rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, 9, &fn);
+    if (rc) return rc;
+    DenseItgArgs args = a;
+    void* params[] = {&args};
+    RK_HIP(hipModuleLaunchKernel(fn, a.B, 1, 1, 256, 1, 1, 0, h->stream, params, nullptr));
+    return RK_OK;
+}
+
 int user_forward(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
     int rc = user_rhs_check(c);
     if (rc) return rc;
@@ -236,8 +258,9 @@ extern "C" {
 int rk_register_rhs_source_m(const char* type_name, const char* source, int32_t n_block, int32_t n_bmeas, int32_t n_theta,
                              int32_t* rhs_id) {
     RK_REQUIRE(type_name && source && rhs_id, RK_ERR_INVALID, "rk_register_rhs_source: null argument");
-    RK_REQUIRE(n_block >= 1 && n_block <= 16 && n_theta >= 0 && n_bmeas >= 1 && n_bmeas <= 4, RK_ERR_INVALID,
-               "rk_register_rhs_source: bad n_block / n_bmeas / n_theta");
+    // (n_bmeas > 4: one block holding all variables, served by the dense path -- solve_dense.hip)
+    RK_REQUIRE(n_block >= 1 && n_block <= 16 && n_theta >= 0 && n_bmeas >= 1 && (n_bmeas <= 4 || (n_block == 1 && n_bmeas <= 256)),
+               RK_ERR_INVALID, "rk_register_rhs_source: bad n_block / n_bmeas / n_theta");
     std::lock_guard<std::mutex> lk(g_mu);
     g_rhs.push_back(UserRhs{type_name, source, n_block, n_theta, n_bmeas});
     *rhs_id = RK_RHS_USER_BASE + (int)g_rhs.size() - 1;
@@ -258,7 +281,8 @@ int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate) 
     }
     std::vector<char> code;
     std::string lowered;
-    return jit_compile(u, n_bstate, interrogate, u.n_bmeas > 1 ? 7 : 0, code, lowered);
+    const bool dense = u.n_block == 1 && u.n_bmeas > 1 && (n_bstate > 9 || u.n_bmeas > 4);      // (user_dense_wanted)
+    return jit_compile(u, n_bstate, interrogate, dense ? 9 : (u.n_bmeas > 1 ? 7 : 0), code, lowered);
 }
 
 }  // extern "C"

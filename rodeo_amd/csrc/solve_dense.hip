@@ -35,6 +35,7 @@
 #include "common.hpp"
 #include "linalg_small.hpp"
 #include "solve_args.hpp"
+#include "solve_dense_itg_kernels.hpp"
 
 namespace rk {
 
@@ -46,6 +47,7 @@ struct DenseArgs {
     double *mean, *var;                        // (B, N+1, p), (B, N+1, p, p)
     double* ws;                                // workspace, ws_stride doubles per trajectory
     size_t ws_stride;
+    int mode, n0;                              // dense_fwd_kernel: 0 = all steps (built-in linear ODE); 1, 2: see there
 };
 
 constexpr int DT = 512, NWAVE = DT / 64;
@@ -947,19 +949,22 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
     const double* Aode = a.theta;
     if (q_bd) load_qd(qd, a.Q, p, nd);
     RK_STAMP_DECL(a.ws + a.ws_stride);
-    RK_STAMP_ZERO();
-    // time 0: (ode_init, 0)   (solve.py:53-54, 114-121)
-    for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
-    for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
+    if (a.mode != 2) {
+        RK_STAMP_ZERO();
+        // time 0: (ode_init, 0)   (solve.py:53-54, 114-121)
+        for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
+        for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
+    }
     __syncthreads();
-    for (int n = 0; n < a.N; ++n) {
+    // The step's dense products are issued from ONE wg_gemm call in a descriptor loop over its phases:
+    // 0-1 predict (standard.py:57-59), 2 mu-, 3 interrogation and W~ Sigma-, 4 S, 5 (Sigma- W~^T)^T (standard.py:93-97),
+    // 6 the LU solve, the mean and Sigma- - K (W~ Sigma-) (standard.py:98-102).
+    auto phases = [&](int n, int ph_lo, int ph_hi) {
         const double* mu = mean + (size_t)n * p;
         const double* Sig = var + (size_t)n * p * p;
         double* mu_o = mean + (size_t)(n + 1) * p;
         double* Sig_o = var + (size_t)(n + 1) * p * p;
-        // phases 0-1: predict (standard.py:57-59); 2-4: W~ Sigma-, S, (Sigma- W~^T)^T (standard.py:93-97);
-        // then the LU solve and the mean; 5: Sigma- - K (W~ Sigma-) (standard.py:101-102)
-        for (int ph = 0; ph < 6; ++ph) {
+        for (int ph = ph_lo; ph < ph_hi; ++ph) {
             GemmOp g;
             bool run = true;
             switch (ph) {
@@ -971,46 +976,55 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                     if (q_bd) { wg_bd_right(w.A2, w.A1, a.R, nullptr, nullptr, p, nd); run = false; }
                     else g = gemm_op(w.A2, p, w.A1, p, false, a.Q, p, true, p, p, p, a.R, p, 1.0, 1.0);
                     break;
-                case 2: {
-                    // ---- interrogation (interrogate.py) for the linear ODE f = A x, x_v = X[v * nd] ----
+                case 2:
                     if (q_bd) wg_bd_matvec(qd, w.mup, mu, p, nd);
                     else wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
-                    for (int e = threadIdx.x; e < m * p; e += DT) {
-                        const int i = e / p, j = e % p;
-                        double Jij = 0.0;
-                        if (a.itg == RK_INTERROGATE_KRAMER && j % nd == 0) {
-                            const int v = j / nd;
-                            Jij = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+                    run = false;
+                    break;
+                case 3: {
+                    // ---- interrogation (interrogate.py): W~ = W - J in w.Wt, the offset a = -f (+ J mu- for kramer,
+                    // interrogate.py:81-82) in w.f.  Built in: the linear ODE f = A x, x_v = X[v * nd]; a right-hand
+                    // side that arrives through hiprtc has filled both from its own kernel between two launches of this
+                    // one (a.mode != 0, solve_dense_itg_kernels.hpp) ----
+                    if (a.mode == 0) {
+                        for (int e = threadIdx.x; e < m * p; e += DT) {
+                            const int i = e / p, j = e % p;
+                            double Jij = 0.0;
+                            if (a.itg == RK_INTERROGATE_KRAMER && j % nd == 0) {
+                                const int v = j / nd;
+                                Jij = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+                            }
+                            w.Wt[e] = a.W[e] + (-Jij);                                   // W + wgt_meas   (solve.py:79)
                         }
-                        w.Wt[e] = a.W[e] + (-Jij);                                   // W + wgt_meas   (solve.py:79)
+                        __syncthreads();
                     }
-                    __syncthreads();
-                    // f_i = sum_v A_iv x_v and yhat = W~ mu- + a ;  a = -f (+ J mu- for kramer, interrogate.py:81-82) with
-                    // J mu- = (W - W~) mu-: one wave per measurement row, lanes along the sums, wave reduction
+                    // yhat = W~ mu- + a (standard.py:93); for the linear ODE f_i = sum_v A_iv x_v and J mu- = (W - W~) mu-:
+                    // one wave per measurement row, lanes along the sums, wave reduction
                     for (int i = threadIdx.x >> 6; i < m; i += DT / 64) {
                         const int lane = threadIdx.x & 63;
                         double s = 0.0, jm = 0.0, wm = 0.0;
-                        for (int v = lane; v < m; v += 64) {
-                            const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
-                            s = fma(Aiv, w.mup[(size_t)v * nd], s);
-                        }
+                        if (a.mode == 0)
+                            for (int v = lane; v < m; v += 64) {
+                                const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+                                s = fma(Aiv, w.mup[(size_t)v * nd], s);
+                            }
                         for (int j = lane; j < p; j += 64) {
                             const double wt = w.Wt[(size_t)i * p + j], mj = w.mup[j];
-                            jm = fma(a.W[(size_t)i * p + j] - wt, mj, jm);
+                            if (a.mode == 0) jm = fma(a.W[(size_t)i * p + j] - wt, mj, jm);
                             wm = fma(wt, mj, wm);
                         }
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) {
                             s += __shfl_xor(s, off); jm += __shfl_xor(jm, off); wm += __shfl_xor(wm, off);
                         }
-                        const double am = a.itg == RK_INTERROGATE_KRAMER ? -s + jm : -s;
-                        if (lane == 0) w.yhat[i] = wm + am;                           // standard.py:93
+                        const double am = a.mode != 0 ? w.f[i] : (a.itg == RK_INTERROGATE_KRAMER ? -s + jm : -s);
+                        if (lane == 0) w.yhat[i] = wm + am;
                     }
                     g = gemm_op(w.WS, p, w.Wt, p, false, w.A2, p, false, m, p, p, nullptr, 0, 0.0, 1.0);          // W~ Sigma-
                     break;
                 }
-                case 3: g = gemm_op(w.S, m, w.WS, p, false, w.Wt, p, true, m, m, p, nullptr, 0, 0.0, 1.0); break;  // (W~ Sigma-) W~^T
-                case 4: g = gemm_op(w.X, p, w.Wt, p, false, w.A2, p, true, m, p, p, nullptr, 0, 0.0, 1.0); break;  // (Sigma- W~^T)^T
+                case 4: g = gemm_op(w.S, m, w.WS, p, false, w.Wt, p, true, m, m, p, nullptr, 0, 0.0, 1.0); break;  // (W~ Sigma-) W~^T
+                case 5: g = gemm_op(w.X, p, w.Wt, p, false, w.A2, p, true, m, p, p, nullptr, 0, 0.0, 1.0); break;  // (Sigma- W~^T)^T
                 default:
                     if (a.itg == RK_INTERROGATE_RODEO) {                              // + var_meas = W Sigma- W^T (W~ = W)
                         for (int e = threadIdx.x; e < m * m; e += DT) w.S[e] = w.S[e] + w.S[e];
@@ -1028,6 +1042,17 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
             if (run) wg_gemm(g);
             RK_STAMP(ph);
         }
+    };
+    // mode 0: the whole forward pass with the built-in linear right-hand side; modes 1, 2: the pieces around the
+    // interrogation kernel of a hiprtc right-hand side (dense_solve): 1 = time 0 and step 0 up to mu-,
+    // 2 = the update of step n0 and step n0 + 1 up to mu-
+    if (a.mode == 0) {
+        for (int n = 0; n < a.N; ++n) phases(n, 0, 7);
+    } else if (a.mode == 1) {
+        phases(0, 0, 3);
+    } else {
+        phases(a.n0, 3, 7);
+        if (a.n0 + 1 < a.N) phases(a.n0 + 1, 0, 3);
     }
 }
 
@@ -1112,8 +1137,14 @@ __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
     }
 }
 
+bool is_user_rhs(int rhs_id);
+bool user_dense_wanted(const rk_solve_cfg* c);
+int user_dense_interrogate(rk_handle h, const rk_solve_cfg* c, const DenseItgArgs& a);
+
+// The built-in linear ODE of config 5, and any hiprtc right-hand side in the non-block form (one block, several
+// measurements) beyond what the lane-per-trajectory kernels take (rhs_jit.hip: n_bstate > 9 or n_bmeas > 4).
 bool dense_supported(const rk_solve_cfg* c, int mode) {
-    return c->rhs_id == RK_RHS_LINEAR_DENSE;
+    return c->rhs_id == RK_RHS_LINEAR_DENSE || (is_user_rhs(c->rhs_id) && user_dense_wanted(c));
 }
 
 int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
@@ -1129,8 +1160,11 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
     RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED), RK_ERR_UNSUPPORTED, "dense path: RK_FLAG_STORE_PRED is not available");
     RK_REQUIRE(!in->ode_weight_batched && !in->prior_weight_batched && !in->prior_var_batched, RK_ERR_UNSUPPORTED,
                "dense path: ode_weight and prior_pars must be shared by all trajectories");
-    RK_REQUIRE(in->theta && c->n_theta == c->n_bmeas * c->n_bmeas, RK_ERR_INVALID,
-               "dense linear ODE needs theta = A (n_vars x n_vars row-major), n_theta = %d", c->n_bmeas * c->n_bmeas);
+    if (c->rhs_id == RK_RHS_LINEAR_DENSE)
+        RK_REQUIRE(in->theta && c->n_theta == c->n_bmeas * c->n_bmeas, RK_ERR_INVALID,
+                   "dense linear ODE needs theta = A (n_vars x n_vars row-major), n_theta = %d", c->n_bmeas * c->n_bmeas);
+    else
+        RK_REQUIRE(c->n_theta == 0 || in->theta, RK_ERR_INVALID, "dense path: theta is NULL but n_theta = %d", c->n_theta);
     return RK_OK;
 }
 
@@ -1151,10 +1185,34 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
     a.x0_b = in->ode_init_batched; a.theta_b = in->theta_batched;
     a.mean = out->mean_state; a.var = out->var_state;
     a.ws = (double*)out->workspace; a.ws_stride = dense_ws_doubles(a.p, a.m);
+    a.mode = 0; a.n0 = 0;
     hipLaunchKernelGGL(dense_qcheck_kernel, dim3(1), dim3(256), 0, h->stream, a.Q, a.p, a.p / a.m, a.ws + a.ws_stride - 1);
-    {
+    if (c->rhs_id == RK_RHS_LINEAR_DENSE) {
         LaunchTimer t(h, "dense_fwd_kernel");
         hipLaunchKernelGGL(dense_fwd_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+        t.stop();
+    } else {
+        // a right-hand side built by hiprtc: the step is cut at the interrogation (solve_dense_itg_kernels.hpp) -- the
+        // precompiled phases on either side, the user's code in between; N + 1 + N launches queued back to back
+        // (a step is ~0.1-1 ms of device work at these sizes)
+        DenseItgArgs g;
+        g.B = a.B; g.N = a.N; g.t_min = a.t_min; g.t_max = a.t_max; g.W = a.W; g.theta = a.theta; g.theta_b = a.theta_b;
+        g.ws = a.ws; g.ws_stride = a.ws_stride;
+        {
+            const size_t pp = (size_t)a.p * a.p, mp = (size_t)a.m * a.p;      // (carve)
+            g.off_Wt = 4 * pp; g.off_mup = 4 * pp + 3 * mp + (size_t)a.m * a.m; g.off_am = g.off_mup + a.p;
+        }
+        LaunchTimer t(h, "dense_fwd_kernel<user, stepwise>");
+        a.mode = 1;
+        hipLaunchKernelGGL(dense_fwd_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+        a.mode = 2;
+        for (int n = 0; n < a.N; ++n) {
+            g.n = n;
+            const int rc = user_dense_interrogate(h, c, g);
+            if (rc) return rc;
+            a.n0 = n;
+            hipLaunchKernelGGL(dense_fwd_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+        }
         t.stop();
     }
     RK_HIP(hipGetLastError());

@@ -123,8 +123,9 @@ def trace_source(fun, n_vars, n_deriv_used, param_spec, struct_name):
     out = np.asarray(out, dtype=object)
     if out.shape == (n_vars,):
         out = out[:, None]
-    if out.ndim != 2 or out.shape[0] != n_vars or not 1 <= out.shape[1] <= 4:
-        raise ValueError(f"the traced ode_fun must return shape ({n_vars}, n_bmeas) with n_bmeas in 1..4, got {out.shape}")
+    m_max = 256 if n_vars == 1 else 4          # one block holding all variables (non-block form): the dense path beyond 4
+    if out.ndim != 2 or out.shape[0] != n_vars or not 1 <= out.shape[1] <= m_max:
+        raise ValueError(f"the traced ode_fun must return shape ({n_vars}, n_bmeas) with n_bmeas in 1..{m_max}, got {out.shape}")
     n_bmeas = out.shape[1]
     lines = []
     for b in range(n_vars):

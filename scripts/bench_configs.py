@@ -90,8 +90,8 @@ def c5(args):
     if os.environ.get("RK_DENSE_STAMPS") == "fwd":
         plan.filter(None); dev.sync()
         ws = plan._ws.to_host().reshape(B, -1)
-        names = ["Q Sigma", "(Q Sigma) Q^T + R", "interrogation + W~ Sigma-", "S", "Sigma- W~^T", "LU + mean + downdate"]
-        print("fwd phase cycles per step (wg 0):", {k: int(v) for k, v in zip(names, ws[0, -2:-8:-1] / N)}, file=sys.stderr)
+        names = ["Q Sigma", "(Q Sigma) Q^T + R", "mu-", "interrogation + W~ Sigma-", "S", "Sigma- W~^T", "LU + mean + downdate"]
+        print("fwd phase cycles per step (wg 0):", {k: int(v) for k, v in zip(names, ws[0, -2:-9:-1] / N)}, file=sys.stderr)
     elif os.environ.get("RK_DENSE_STAMPS"):
         ws = plan._ws.to_host().reshape(B, -1)
         names = ["predict+T+diff", "LU panel", "LU swaps", "LU trsm", "LU gemm", "back trsm", "back gemm", "mean", "G D", "GDG^T"]

@@ -236,3 +236,74 @@ def test_dense_batched_ode_matrix(ra):
             mo, vo = scan.solve_mv(None, odes.make_linear_dense(A[b], n_deriv), s["W"], X0[b], 0.0, t_max, N, o, s["prior"])
             scale_m = np.max(np.abs(mo), axis=(0, 1))
             assert np.max(np.abs(m[b] - mo) / np.maximum(scale_m, 1e-300)) < tol
+
+
+def _ring_problem(ra, n_vars, n_deriv, N, t_max, B, seed=5):
+    """A nonlinear coupled ring x_i' = -k0 x_i + k1 sin(x_{i+1}) - 0.1 x_i^3 + 0.05 cos t in the reference's NON-BLOCK
+    form: one block of n_vars * n_deriv states, ode_weight (1, n_vars, p), an ordinary Python ode_fun returning
+    (1, n_vars) -- what examples/solve_nb.py does with its own ODEs."""
+    rng = np.random.default_rng(seed)
+    p = n_vars * n_deriv
+    idx0 = np.arange(n_vars) * n_deriv
+
+    def fun(X, t, kc):
+        x = X[0, ::n_deriv]
+        return np.array([[-kc[0] * x[i] + kc[1] * np.sin(x[(i + 1) % n_vars]) - 0.1 * x[i] ** 3 + 0.05 * np.cos(t)
+                          for i in range(n_vars)]])
+
+    def host(X, t, kc):
+        kc = np.asarray(kc, dtype=np.float64)
+        x = X[..., 0, idx0]
+        k0, k1 = kc[..., 0:1], kc[..., 1:2]
+        return (-k0 * x + k1 * np.sin(np.roll(x, -1, axis=-1)) - 0.1 * x ** 3 + 0.05 * np.cos(t))[..., None, :]
+
+    def jac(X, t, kc):
+        kc = np.asarray(kc, dtype=np.float64)
+        x = X[..., 0, idx0]
+        J = np.zeros(X.shape[:-2] + (1, n_vars, p))
+        for i in range(n_vars):
+            J[..., 0, i, idx0[i]] = -kc[..., 0] - 0.3 * x[..., i] ** 2
+            J[..., 0, i, idx0[(i + 1) % n_vars]] += kc[..., 1] * np.cos(x[..., (i + 1) % n_vars])
+        return J
+    Wb, _ = ra.utils.first_order_pad(lambda x, t: x, n_vars, n_deriv)
+    W = block_diag(*[w for w in Wb])[None]
+    prior = ra.indep_init(ra.ibm_init(t_max / N, n_deriv, 0.5 * np.ones(n_vars)))
+    kc = np.array([0.8, 0.6]) * np.exp(0.1 * rng.standard_normal((B, 2)))
+    xv = 0.5 * rng.standard_normal((B, n_vars))
+    X0 = np.zeros((B, n_vars, n_deriv))
+    X0[..., 0] = xv
+    X0 = X0.reshape(B, 1, p)
+    X0[:, 0, idx0 + 1] = host(X0, 0.0, kc)[:, 0, :]               # x' = f(x, 0)
+    return dict(fun=fun, o_ode=odes.ODE("ring_nb", 1, n_vars, host, jac), W=W, prior=prior, kc=kc, x0=X0)
+
+
+@pytest.mark.parametrize("n_vars,n_deriv,itg,N", [(8, 3, "rodeo", 30), (8, 3, "kramer", 4), (8, 3, "schober", 4),
+                                                   (5, 2, "rodeo", 30), (20, 4, "rodeo", 12), (20, 4, "kramer", 3)])
+def test_dense_path_takes_any_traced_ode_fun(ra, n_vars, n_deriv, itg, N):
+    """The non-block form with an ordinary (nonlinear, time-dependent, parametrised) Python ode_fun beyond the sizes of
+    the lane kernels: traced, its dense Jacobian by forward-mode duals (one direction per thread), run on the dense MFMA
+    path with the step cut at the interrogation (solve_dense_itg_kernels.hpp); solve_mv and the filter against the
+    oracle with the analytic Jacobian.  Exact-measurement interrogations over a few steps only (see test_dense_parity)."""
+    from rodeo_amd import _lib
+    B, t_max = 3, N / 30.0
+    s = _ring_problem(ra, n_vars, n_deriv, N, t_max, B)
+    g, o = getattr(ra.interrogate, "interrogate_" + itg), getattr(oi, "interrogate_" + itg)
+    plan = ra.SolvePlan(s["fun"], s["W"], s["x0"], 0.0, t_max, N, g, s["prior"], kc=s["kc"])
+    plan.mv(None)
+    assert plan.layout == _lib.LAYOUT_TRAJ_MAJOR
+    plan.dev.profile_enable(True)
+    plan.mv(None)
+    assert [k for k, _ in plan.dev.profile_last()] == ["dense_fwd_kernel<user, stepwise>", "dense_bwd_mv_kernel"]
+    plan.dev.profile_enable(False)
+    m, v = plan.state_host()
+    mo, vo = scan.solve_mv(None, s["o_ode"], s["W"], s["x0"], 0.0, t_max, N, o, s["prior"], kc=s["kc"])
+    p = n_vars * n_deriv
+    assert m.shape == (B, N + 1, 1, p) and v.shape == (B, N + 1, 1, p, p)
+    scale_m = np.maximum(np.max(np.abs(mo), axis=(0, 1, 2)), 1e-3)
+    assert np.max(np.abs(m - mo) / scale_m) < 1e-7
+    dv = np.sqrt(np.abs(np.einsum("bnkii->bnki", vo)).max(axis=(0, 1, 2)))
+    assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :] + 1e-300)) < 1e-5
+    plan.filter(None)
+    mf, _ = plan.state_host()
+    fo = scan.solve_filter(None, s["o_ode"], s["W"], s["x0"], 0.0, t_max, N, o, *s["prior"], kc=s["kc"])
+    assert np.max(np.abs(mf - fo["state_filt"][0]) / scale_m) < 1e-7

@@ -99,6 +99,28 @@ def test_trace_python_rhs_to_source_and_compile():
         trace.trace_source(lambda X, t: np.array([[abs(X[0, 0]) if X[0, 0] > 0 else 0.0]]), 1, 2, (), "Bad")
 
 
+def test_non_block_form_beyond_the_lane_kernels_builds_the_dense_interrogation_kernel():
+    """An ode_fun in the reference's non-block form (X (1, p) -> (1, n_vars), prior.indep_init) with more states than the
+    lane-per-trajectory kernels take: traced, and hiprtc builds the dense path's interrogation kernel around it
+    (csrc/solve_dense_itg_kernels.hpp) -- no GPU needed for the build.  Several blocks keep the limit of four measurements."""
+    import rodeo_amd as ra
+    from rodeo_amd import _lib, trace
+    n_vars, n_deriv = 8, 3
+
+    def ring(X, t, kc):
+        x = X[0, ::n_deriv]
+        return np.array([[-kc[0] * x[i] + kc[1] * np.sin(x[(i + 1) % n_vars]) - 0.1 * x[i] ** 3 + 0.05 * np.cos(t)
+                          for i in range(n_vars)]])
+    dev = trace.from_python(ring, 1, n_vars * n_deriv, kc=2)
+    assert (dev.n_block, dev.n_bmeas) == (1, n_vars) and "static constexpr int M = 8;" in dev.source
+    for itg in (_lib.INTERROGATE_KRAMER, _lib.INTERROGATE_SCHOBER, _lib.INTERROGATE_RODEO):
+        ra.ode.compile_check(dev, n_vars * n_deriv, itg)
+    out = dev(np.zeros((1, n_vars * n_deriv)), 0.0, kc=np.array([1.0, 1.0]))
+    assert out.shape == (1, n_vars) and np.allclose(out, 0.05)
+    with pytest.raises(ValueError):
+        trace.trace_source(lambda X, t: np.array([[X[0, 0]] * 5, [X[1, 0]] * 5]), 2, 2, (), "FiveMeasurementsTwoBlocks")
+
+
 def test_first_order_pad_with_plain_python_function_is_batch_safe():
     """utils.first_order_pad on the reference's own kind of ode_fun (written for one trajectory): a batch of initial
     values and parameters is evaluated per element, and equals the built-in functor's initialisation."""
