@@ -123,7 +123,7 @@ int rk_register_rhs_source(const char* type_name, const char* source, int32_t n_
  * `type_name` then names a type with the interface of csrc/solve_small_m_kernels.hpp (rk::AutoJacM<...> around a
  * scalar-generic rhs writing out[D][M]); such right-hand sides run on the lane-per-trajectory kernels (n_bstate <= 9,
  * n_bmeas <= 4) or, for ONE block beyond that (n_bmeas up to 256, n_bstate up to 768), on the dense MFMA path with its
- * interrogation kernel built around them (csrc/solve_dense_itg_kernels.hpp; solve_mv / filter, kramer / schober / rodeo). */
+ * interrogation kernel built around them (csrc/solve_dense_itg_kernels.hpp; standard filter, all solvers and interrogations). */
 int rk_register_rhs_source_m(const char* type_name, const char* source, int32_t n_block, int32_t n_bmeas, int32_t n_theta,
                              int32_t* rhs_id);
 int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate);

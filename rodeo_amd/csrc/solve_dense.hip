@@ -2,9 +2,12 @@
 // dense block of n_vars * n_deriv states with n_bmeas = n_vars measurements; examples/solve_nb.py:55-260 is the
 // reference's own statement of this path).  One 512-thread workgroup (8 waves, one per CU) per trajectory runs the
 // whole time loop of
-//   src/rodeo/solve.py:31-122 (forward)  and  src/rodeo/solve.py:257-301 (backward mean/variance smoother)
+//   src/rodeo/solve.py:31-122 (forward),  src/rodeo/solve.py:257-301 (backward mean/variance smoother)  and
+//   src/rodeo/solve.py:137-205 (backward sampler of solve_sim)
 // with every p x p operand in global memory and fp64 MFMA products; all LU solves use partial pivoting like
-// src/rodeo/utils.py:119.
+// src/rodeo/utils.py:119.  Right-hand sides: the linear ODE of config 5 inside the kernels; any other one through an
+// interrogation kernel that hiprtc builds around it, launched between the two halves of the forward step
+// (solve_dense_itg_kernels.hpp).  All four interrogations (interrogate.py:13-115).
 //
 // Layout: trajectory-major = the reference's own layout with a leading batch axis:
 //   mean (B, N+1, p), var (B, N+1, p, p)  (n_block = 1), so a workgroup streams contiguous p x p matrices.
@@ -36,6 +39,7 @@
 #include "linalg_small.hpp"
 #include "solve_args.hpp"
 #include "solve_dense_itg_kernels.hpp"
+#include "philox.hpp"
 
 namespace rk {
 
@@ -48,6 +52,8 @@ struct DenseArgs {
     double* ws;                                // workspace, ws_stride doubles per trajectory
     size_t ws_stride;
     int mode, n0;                              // dense_fwd_kernel: 0 = all steps (built-in linear ODE); 1, 2: see there
+    unsigned long long seed, traj_offset;      // Philox stream of the draws (interrogate_chkrebtii, solve_sim)
+    double* x;                                 // solve_sim: draws, batch-minor like the lane kernels: x[(n p + i) B + b]
 };
 
 constexpr int DT = 512, NWAVE = DT / 64;
@@ -783,6 +789,64 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Draws x = mean + F z with F F^T = A, A symmetric positive SEMI-definite (interrogate_chkrebtii, interrogate.py:30-34;
+// solve_sim, solve.py:182-194): the reference's multivariate_normal takes the Cholesky factor; a non-positive pivot zeroes
+// its column here instead of producing NaN (the rule of the small-block kernels' psd_factor, linalg_small.hpp, and of
+// the oracle).  The factor is built TRANSPOSED, U[j][i] = F[i][j], from the lower triangle of A, so that in the
+// left-looking sweep the thread of row i reads U[k][i] -- consecutive threads, consecutive addresses -- and the pivot
+// row entry U[k][j] is one address for the whole workgroup.  A is not modified.  z: p standard normals in g_lds.
+__device__ __noinline__ void wg_psd_draw(const double* A_, double* U_, const double* mean_, double* x_, int n_, int zoff_) {
+    auto* const A = uni_g(A_);
+    auto* const U = uni_g(U_);
+    auto* const mean = uni_g(mean_);
+    auto* const x = uni_g(x_);
+    const int n = uni(n_), zoff = uni(zoff_);
+    double* const piv = g_rowbuf;                          // [0]: the column's pivot
+    for (int e = threadIdx.x; e < n * n; e += DT) {        // U[j][i] = A[i][j] for i >= j (the lower triangle, transposed)
+        const int j = e / n, i = e - j * n;
+        if (i >= j) U[(size_t)j * n + i] = A[(size_t)i * n + j];
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        double sv[(LU_MAXN * 3 + DT - 1) / DT];            // this thread's rows i = j + threadIdx.x + r DT (n <= 768)
+        int r = 0;
+        for (int i = j + threadIdx.x; i < n; i += DT, ++r) {
+            double acc = U[(size_t)j * n + i];
+            for (int k = 0; k < j; ++k) acc = fma(-U[(size_t)k * n + i], U[(size_t)k * n + j], acc);
+            sv[r] = acc;
+            if (i == j) piv[0] = acc;
+        }
+        __syncthreads();
+        const double d = piv[0];
+        const bool ok = d > 0.0;
+        const double dj = sqrt(ok ? d : 1.0);
+        r = 0;
+        for (int i = j + threadIdx.x; i < n; i += DT, ++r)
+            U[(size_t)j * n + i] = ok ? (i == j ? dj : sv[r] / dj) : 0.0;
+        __syncthreads();
+    }
+    const double* const z = g_lds + zoff;
+    for (int i = threadIdx.x; i < n; i += DT) {
+        double acc = 0.0;
+        for (int j = 0; j <= i; ++j) acc = fma(U[(size_t)j * n + i], z[j], acc);
+        x[i] = mean[i] + acc;
+    }
+    __syncthreads();
+}
+
+// p standard normals of (trajectory, step, block 0, purpose) into g_lds[zoff ..] -- the stream of the small-block kernels
+// and of oracle/counter_rng.py: element 2c, 2c + 1 = the pair of counter c
+__device__ __forceinline__ void wg_normals(unsigned long long seed, unsigned traj, unsigned step, unsigned purpose, int p, int zoff) {
+    for (int c = threadIdx.x; c < (p + 1) / 2; c += DT) {
+        double z0, z1;
+        normal_pair(seed, traj, step, 0u, purpose, (unsigned)c, z0, z1);
+        g_lds[zoff + 2 * c] = z0;
+        if (2 * c + 1 < p) g_lds[zoff + 2 * c + 1] = z1;
+    }
+    __syncthreads();
+}
+
 struct DenseWs {
     double *A1, *A2, *A3, *A4, *Wt, *WS, *X, *S, *mup, *f, *yhat, *dm;
     int* piv;
@@ -979,6 +1043,12 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                 case 2:
                     if (q_bd) wg_bd_matvec(qd, w.mup, mu, p, nd);
                     else wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
+                    if (a.itg == RK_INTERROGATE_CHKREBTII) {
+                        // interrogate.py:22-34: the point the ODE is evaluated at, x ~ N(mu-, Sigma-), into w.dm
+                        __syncthreads();
+                        wg_normals(a.seed, (unsigned)(a.traj_offset + (unsigned long long)b), (unsigned)n, PURPOSE_INTERROGATE, p, 0);
+                        wg_psd_draw(w.A2, w.A3, w.mup, w.dm, p, 0);
+                    }
                     run = false;
                     break;
                 case 3: {
@@ -1003,11 +1073,13 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                     for (int i = threadIdx.x >> 6; i < m; i += DT / 64) {
                         const int lane = threadIdx.x & 63;
                         double s = 0.0, jm = 0.0, wm = 0.0;
-                        if (a.mode == 0)
+                        if (a.mode == 0) {
+                            const double* const xe = a.itg == RK_INTERROGATE_CHKREBTII ? w.dm : w.mup;     // where f is evaluated
                             for (int v = lane; v < m; v += 64) {
                                 const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
-                                s = fma(Aiv, w.mup[(size_t)v * nd], s);
+                                s = fma(Aiv, xe[(size_t)v * nd], s);
                             }
+                        }
                         for (int j = lane; j < p; j += 64) {
                             const double wt = w.Wt[(size_t)i * p + j], mj = w.mup[j];
                             if (a.mode == 0) jm = fma(a.W[(size_t)i * p + j] - wt, mj, jm);
@@ -1026,7 +1098,7 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                 case 4: g = gemm_op(w.S, m, w.WS, p, false, w.Wt, p, true, m, m, p, nullptr, 0, 0.0, 1.0); break;  // (W~ Sigma-) W~^T
                 case 5: g = gemm_op(w.X, p, w.Wt, p, false, w.A2, p, true, m, p, p, nullptr, 0, 0.0, 1.0); break;  // (Sigma- W~^T)^T
                 default:
-                    if (a.itg == RK_INTERROGATE_RODEO) {                              // + var_meas = W Sigma- W^T (W~ = W)
+                    if (a.itg == RK_INTERROGATE_RODEO || a.itg == RK_INTERROGATE_CHKREBTII) {   // + var_meas = W Sigma- W^T (W~ = W; interrogate.py:110-113, 26-29)
                         for (int e = threadIdx.x; e < m * m; e += DT) w.S[e] = w.S[e] + w.S[e];
                         __syncthreads();
                     }
@@ -1137,6 +1209,77 @@ __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward sampler of solve_sim (solve.py:137-205, standard.py:248-254) on the filtered moments, which stay untouched:
+//   x_N ~ N(mu_N, Sigma_N);   x_n ~ N(mu_f + G (x_{n+1} - mu-),  Sigma_f - G T^T),   T = Sigma_f Q^T, G = T (Sigma-)^{-1},
+// with the building blocks of the smoothing pass above and the factor / draw of wg_psd_draw.  x[0] = ode_init.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DT) dense_bwd_sim_kernel(DenseArgs a) {
+    double* const qd = g_qd;
+    double* const lds = g_lds;
+    const int b = blockIdx.x, p = a.p, m = a.m;
+    const int nd = p / m;
+    const DenseWs w = carve(a.ws + (size_t)b * a.ws_stride, p, m);
+    const bool q_bd = a.ws[a.ws_stride - 1] != 0.0;
+    const double* mean = a.mean + (size_t)b * (a.N + 1) * p;
+    const double* var = a.var + (size_t)b * (a.N + 1) * p * p;
+    const unsigned traj = (unsigned)(a.traj_offset + (unsigned long long)b);
+    if (q_bd) load_qd(qd, a.Q, p, nd);
+    auto put_x = [&](int n, const double* xv) {
+        for (int i = threadIdx.x; i < p; i += DT) a.x[((size_t)n * p + i) * a.B + b] = xv[i];
+    };
+    // terminal draw (solve.py:182-186)
+    wg_normals(a.seed, traj, (unsigned)a.N, PURPOSE_SMOOTH, p, 0);
+    wg_psd_draw(var + (size_t)a.N * p * p, w.A3, mean + (size_t)a.N * p, w.dm, p, 0);
+    put_x(a.N, w.dm);                                           // w.dm = x_{n+1} from here on
+    __syncthreads();
+    for (int n = a.N - 1; n >= 1; --n) {
+        const double* mu_f = mean + (size_t)n * p;
+        const double* Sig_f = var + (size_t)n * p * p;
+        // pred[n+1] from filt[n]; T^T = Q Sigma_f^T (standard.py:175)
+        if (q_bd) {
+            wg_bd_left(w.A1, Sig_f, w.A3, Sig_f, p, nd);
+            wg_bd_right(w.A2, w.A1, a.R, nullptr, nullptr, p, nd);
+        } else {
+            wg_gemm(gemm_op(w.A1, p, a.Q, p, false, Sig_f, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
+            wg_gemm(gemm_op(w.A2, p, w.A1, p, false, a.Q, p, true, p, p, p, a.R, p, 1.0, 1.0));
+            wg_gemm(gemm_op(w.A3, p, a.Q, p, false, Sig_f, p, true, p, p, p, nullptr, 0, 0.0, 1.0));
+        }
+        if (q_bd) wg_bd_matvec(qd, w.mup, mu_f, p, nd);
+        else wg_gemv<false>(w.mup, a.Q, p, mu_f, p, p, nullptr, 0.0, 1.0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < p * p; e += DT) w.A4[e] = w.A3[e];          // keep T^T: the solve overwrites A3
+        for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = w.dm[i] - w.mup[i];   // x_{n+1} - mu-
+        __syncthreads();
+        wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv, a.ws + a.ws_stride);           // A3 <- G^T (standard.py:176)
+        // mean_sim = mu_f + G (x_{n+1} - mu-) (standard.py:250-251): column sums of G^T through LDS, as in the smoother
+        {
+            const int ng = DT / 64;
+            for (int i = threadIdx.x & 63; i < p; i += 64) {
+                const int gq = threadIdx.x >> 6;
+                double sacc = 0.0;
+                #pragma unroll 8
+                for (int j = gq; j < p; j += ng) sacc = fma(w.A3[(size_t)j * p + i], w.dm[j], sacc);
+                lds[gq * p + i] = sacc;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < p; i += DT) {
+                double sacc = 0.0;
+                for (int gq = 0; gq < ng; ++gq) sacc += lds[gq * p + i];
+                w.mup[i] = mu_f[i] + sacc;                                         // mean_sim (mu- is no longer needed)
+            }
+            __syncthreads();
+        }
+        wg_gemm(gemm_op(w.A1, p, w.A3, p, true, w.A4, p, false, p, p, p, Sig_f, p, 1.0, -1.0));   // Sigma_f - G T^T (standard.py:252-253)
+        wg_normals(a.seed, traj, (unsigned)n, PURPOSE_SMOOTH, p, 0);
+        wg_psd_draw(w.A1, w.A2, w.mup, w.dm, p, 0);                                // x_n -> w.dm
+        put_x(n, w.dm);
+        __syncthreads();
+    }
+    put_x(0, mean);                                             // x[0] = ode_init exactly (solve.py:196-204)
+    (void)m;
+}
+
 bool is_user_rhs(int rhs_id);
 bool user_dense_wanted(const rk_solve_cfg* c);
 int user_dense_interrogate(rk_handle h, const rk_solve_cfg* c, const DenseItgArgs& a);
@@ -1153,9 +1296,6 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
                "dense linear ODE: n_bstate (%d) must be n_vars * n_deriv with n_vars = n_bmeas (%d), n_deriv >= 2",
                c->n_bstate, c->n_bmeas);
     RK_REQUIRE(c->n_bstate <= 768, RK_ERR_UNSUPPORTED, "dense path: n_bstate = %d exceeds 768 (LDS staging of the GEMMs)", c->n_bstate);
-    RK_REQUIRE(mode != RK_MODE_SIM, RK_ERR_UNSUPPORTED, "dense path: solve_sim is not available yet");
-    RK_REQUIRE(c->interrogate != RK_INTERROGATE_CHKREBTII, RK_ERR_UNSUPPORTED,
-               "dense path: interrogate_chkrebtii is not available yet");
     RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "dense path: kalman_type must be standard");
     RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED), RK_ERR_UNSUPPORTED, "dense path: RK_FLAG_STORE_PRED is not available");
     RK_REQUIRE(!in->ode_weight_batched && !in->prior_weight_batched && !in->prior_var_batched, RK_ERR_UNSUPPORTED,
@@ -1186,6 +1326,8 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
     a.mean = out->mean_state; a.var = out->var_state;
     a.ws = (double*)out->workspace; a.ws_stride = dense_ws_doubles(a.p, a.m);
     a.mode = 0; a.n0 = 0;
+    a.seed = c->seed; a.traj_offset = c->traj_offset; a.x = out->x_state;
+    RK_REQUIRE(mode != RK_MODE_SIM || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");
     hipLaunchKernelGGL(dense_qcheck_kernel, dim3(1), dim3(256), 0, h->stream, a.Q, a.p, a.p / a.m, a.ws + a.ws_stride - 1);
     if (c->rhs_id == RK_RHS_LINEAR_DENSE) {
         LaunchTimer t(h, "dense_fwd_kernel");
@@ -1201,6 +1343,7 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
         {
             const size_t pp = (size_t)a.p * a.p, mp = (size_t)a.m * a.p;      // (carve)
             g.off_Wt = 4 * pp; g.off_mup = 4 * pp + 3 * mp + (size_t)a.m * a.m; g.off_am = g.off_mup + a.p;
+            g.off_x = c->interrogate == RK_INTERROGATE_CHKREBTII ? g.off_mup + a.p + 2 * (size_t)a.m : g.off_mup;    // w.dm / w.mup
         }
         LaunchTimer t(h, "dense_fwd_kernel<user, stepwise>");
         a.mode = 1;
@@ -1216,6 +1359,12 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
         t.stop();
     }
     RK_HIP(hipGetLastError());
+    if (mode == RK_MODE_SIM) {
+        LaunchTimer t(h, "dense_bwd_sim_kernel");
+        hipLaunchKernelGGL(dense_bwd_sim_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+        t.stop();
+        RK_HIP(hipGetLastError());
+    }
     if (mode == RK_MODE_MV && a.N >= 2) {
         LaunchTimer t(h, "dense_bwd_mv_kernel");
         hipLaunchKernelGGL(dense_bwd_mv_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);

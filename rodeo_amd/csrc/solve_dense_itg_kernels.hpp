@@ -22,7 +22,7 @@ struct DenseItgArgs {
     const double* theta;             // (n_theta[, B]) or null
     int theta_b;
     double* ws;                      // dense workspace; per trajectory ws_stride doubles
-    size_t ws_stride, off_mup, off_Wt, off_am;
+    size_t ws_stride, off_mup, off_Wt, off_am, off_x;      // off_x: where f is evaluated (mu-, or chkrebtii's draw)
 };
 
 template <class U, int P, int ITG>
@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(256) dense_interrogate_kernel(DenseItgArgs a) 
     const int b = blockIdx.x;
     double* const w = a.ws + (size_t)b * a.ws_stride;
     const double* const mup = w + a.off_mup;
+    const double* const xe = w + a.off_x;          // mu- (kramer, schober, rodeo) or x ~ N(mu-, Sigma-) (chkrebtii, interrogate.py:30-34)
     double* const Wt = w + a.off_Wt;
     double* const am = w + a.off_am;
     __shared__ double fv[M];
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(256) dense_interrogate_kernel(DenseItgArgs a) 
         Dual<1> X[1][P], out[1][M];
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            X[0][k] = Dual<1>(mup[k]);             // (entries the function does not read are dropped by the compiler)
+            X[0][k] = Dual<1>(xe[k]);              // (entries the function does not read are dropped by the compiler)
             X[0][k].d[0] = k == j ? 1.0 : 0.0;
         }
         U::template rhs<Dual<1>, P>(X, t, th, out);

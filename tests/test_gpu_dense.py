@@ -77,9 +77,9 @@ def test_dense_matches_exact_solution_and_api(ra):
     exact = expm(s["A"] * t_max) @ s["x0v"]
     assert np.max(np.abs(m[-1, 0, ::n_deriv] - exact)) < 1e-3
     from rodeo_amd._lib import RodeoKalmanError
-    with pytest.raises(RodeoKalmanError):
-        ra.solve_sim(1, ra.ode.linear_dense(n_vars, n_deriv), s["W"], s["x0"], 0.0, t_max, N,
-                     ra.interrogate.interrogate_kramer, s["prior"], A=s["A"])
+    with pytest.raises(RodeoKalmanError):                      # the dense path has no square-root form
+        ra.solve_mv(None, ra.ode.linear_dense(n_vars, n_deriv), s["W"], s["x0"], 0.0, t_max, N,
+                    ra.interrogate.interrogate_kramer, s["prior"], kalman_type="square-root", A=s["A"])
 
 
 def test_config5_full_size_properties(ra):
@@ -307,3 +307,53 @@ def test_dense_path_takes_any_traced_ode_fun(ra, n_vars, n_deriv, itg, N):
     mf, _ = plan.state_host()
     fo = scan.solve_filter(None, s["o_ode"], s["W"], s["x0"], 0.0, t_max, N, o, *s["prior"], kc=s["kc"])
     assert np.max(np.abs(mf - fo["state_filt"][0]) / scale_m) < 1e-7
+
+
+@pytest.mark.parametrize("n_vars,n_deriv,N", [(4, 3, 16), (6, 3, 12), (24, 3, 6), (14, 5, 5)])
+def test_dense_chkrebtii_and_solve_sim(ra, n_vars, n_deriv, N):
+    """interrogate_chkrebtii (x ~ N(mu-, Sigma-) through the PSD-safe Cholesky factor, interrogate.py:22-34) and solve_sim
+    (solve.py:137-205: terminal draw, backward draws from N(mu_f + G (x - mu-), Sigma_f - G T^T)) on the dense path, built-in
+    linear right-hand side, against the oracle with the shared Philox stream."""
+    import functools
+    t_max, B = N / 24.0, 3
+    s = dense_problem(ra, n_vars, n_deriv, N, t_max, B=B)
+    ode_d, ode_o = ra.ode.linear_dense(n_vars, n_deriv), odes.make_linear_dense(s["A"], n_deriv)
+    p = n_vars * n_deriv
+    g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="standard")
+    o = functools.partial(oi.interrogate_chkrebtii, kalman_type="standard")
+    plan = ra.SolvePlan(ode_d, s["W"], s["x0"], 0.0, t_max, N, g, s["prior"], A=s["A"])
+    plan.mv(7)
+    m, v = plan.state_host()
+    mo, vo = scan.solve_mv(7, ode_o, s["W"], s["x0"], 0.0, t_max, N, o, s["prior"])
+    scale_m = np.maximum(np.max(np.abs(mo), axis=(0, 1, 2)), 1e-3)
+    assert np.max(np.abs(m - mo) / scale_m) < 1e-7
+    dv = np.sqrt(np.abs(np.einsum("bnkii->bnki", vo)).max(axis=(0, 1, 2)))
+    assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :] + 1e-300)) < 1e-5
+    plan.mv(8)
+    assert np.max(np.abs(plan.state_host()[0] - m)) > 0          # another key, another path
+    for gg, oo, key in ((ra.interrogate.interrogate_rodeo, oi.interrogate_rodeo, 3), (g, o, 4)):
+        x = ra.solve_sim(key, ode_d, s["W"], s["x0"], 0.0, t_max, N, gg, s["prior"], A=s["A"])
+        xo = scan.solve_sim(key, ode_o, s["W"], s["x0"], 0.0, t_max, N, oo, s["prior"])
+        assert x.shape == (B, N + 1, 1, p)
+        np.testing.assert_array_equal(x[:, 0], s["x0"])
+        sx = np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1e-3)
+        assert np.max(np.abs(x - xo) / sx) < 1e-6
+
+
+def test_dense_traced_ode_fun_chkrebtii_and_solve_sim(ra):
+    """The same two on the dense path with a traced nonlinear ode_fun (the run-time-built interrogation kernel evaluates f at
+    the draw)."""
+    import functools
+    n_vars, n_deriv, N, B = 8, 3, 16, 3
+    t_max = N / 30.0
+    s = _ring_problem(ra, n_vars, n_deriv, N, t_max, B)
+    g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="standard")
+    o = functools.partial(oi.interrogate_chkrebtii, kalman_type="standard")
+    args = (s["W"], s["x0"], 0.0, t_max, N)
+    m, v = ra.solve_mv(5, s["fun"], *args, g, s["prior"], kc=s["kc"])
+    mo, vo = scan.solve_mv(5, s["o_ode"], *args, o, s["prior"], kc=s["kc"])
+    scale_m = np.maximum(np.max(np.abs(mo), axis=(0, 1, 2)), 1e-3)
+    assert np.max(np.abs(m - mo) / scale_m) < 1e-7
+    x = ra.solve_sim(6, s["fun"], *args, g, s["prior"], kc=s["kc"])
+    xo = scan.solve_sim(6, s["o_ode"], *args, o, s["prior"], kc=s["kc"])
+    assert np.max(np.abs(x - xo) / np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1e-3)) < 1e-6
