@@ -584,3 +584,46 @@ def test_square_root_solver_traced_python_rhs_and_higher_n_deriv(ra, p):
     x = ra.solve_sim(3, fitz, *args, ra.interrogate.interrogate_rodeo, pr, kalman_type="square-root", theta=s["theta"])
     xo = scan.solve_sim(3, odes.fitzhugh_nagumo, *args, oi.interrogate_rodeo, pr, kalman_type="square-root", theta=s["theta"])
     assert np.max(np.abs(x - xo) / np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1.0)) < 1e-6
+
+
+def test_tile4_backward_chunk_boundaries_and_ragged_waves(ra):
+    """bwd_mv_tile4_kernel around every special case of its chunked hand-off (chunks of 12 steps with four tiles per wave,
+    16 with three; the last two chunks flushed by the consumer itself, the others by the stage-3 producer wave; a ragged
+    last chunk stored element by element; row images with pieces masked for tiles past the end): tile path against the
+    lane-per-trajectory kernels on the same inputs, many (n_block, batch, steps)."""
+    from rodeo_amd import _lib
+    g = ra.interrogate.interrogate_rodeo
+    worst = 0.0
+    for prob, Bs, Ns in (("fitz4", (1, 2, 3, 5, 7), (2, 3, 12, 13, 14, 24, 25, 26, 36, 37, 38, 49, 61)),
+                         ("higher", (1, 3, 5, 9), (2, 13, 25, 37, 50)),
+                         ("lorenz", (1, 2, 5), (2, 3, 16, 17, 18, 32, 33, 34, 48, 49, 50, 65, 81))):
+        for B in Bs:
+            for N in Ns:
+                rng = np.random.default_rng(B * 1000 + N)
+                if prob == "lorenz":
+                    theta = np.array([28., 10., 8. / 3.]) * np.exp(0.01 * rng.standard_normal((B, 3)))
+                    W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, 4)
+                    x0 = init(np.array([-12., -5., 38.]) + 0.1 * rng.standard_normal((B, 3)), 0.0, theta=theta)
+                    t_max, prior, dode, kw = N * 1e-3, ra.ibm_init(1e-3, 4, np.array([5e7] * 3)), ra.ode.lorenz63, dict(theta=theta)
+                elif prob == "fitz4":
+                    s = fitz_problem(ra, N=N, t_max=N * 0.05, sigma=.1, p=4, B=B, seed=N)
+                    W, x0, prior, t_max, dode, kw = s["W"], s["x0"], s["prior"], s["t_max"], ra.ode.fitzhugh_nagumo, dict(theta=s["theta"])
+                else:
+                    W = np.array([[[0., 0., 1., 0.]]])
+                    x0 = np.tile(np.array([[-1., 0., 1., 0.]]), (B, 1, 1)) + 0.01 * rng.standard_normal((B, 1, 4))
+                    t_max, prior, dode, kw = N * 0.05, ra.ibm_init(0.05, 4, np.array([.01])), ra.ode.higher_order, {}
+                args = (W, x0, 0.0, t_max, N)
+                pt = ra.SolvePlan(dode, *args, g, prior, **kw)
+                pt.mv(None)
+                assert pt.layout == _lib.LAYOUT_TILE4
+                m, v = pt.state_host()
+                pb = ra.SolvePlan(dode, *args, g, prior, batch_minor=True, **kw)
+                pb.mv(None)
+                m2, v2 = pb.state_host()
+                sm = np.maximum(np.max(np.abs(m2), axis=(0, 1, 2)), 1e-12)
+                sd = np.sqrt(np.max(np.abs(np.einsum("bnkii->bnki", v2)), axis=(0, 1, 2))) + 1e-300
+                em, ev = np.max(np.abs(m - m2) / sm), np.max(np.abs(v - v2) / (sd[:, None] * sd[None, :]))
+                assert np.all(np.isfinite(m)) and np.all(np.isfinite(v)) and em < 1e-8 and ev < 1e-7, (prob, B, N, em, ev)
+                worst = max(worst, em, ev)
+                del pt, pb
+    assert worst < 1e-7
