@@ -159,7 +159,8 @@ typedef struct {
     /* filtered moments; after rk_solve_mv they hold the SMOOTHED moments (smoothing is done in place)      */
     double* mean_state;     /* (N+1, d, p, B)                                                               */
     double* var_state;      /* (N+1, d, p, p, B)                                                            */
-    /* predicted moments, only written when RK_FLAG_STORE_PRED is set (may be NULL otherwise)               */
+    /* predicted moments, only written when RK_FLAG_STORE_PRED is set (may be NULL otherwise); with          */
+    /* RK_LAYOUT_TRAJ_MAJOR (the dense path) they are trajectory-major like the state: (B, N+1, p[, p])     */
     double* mean_pred;      /* (N+1, d, p, B)                                                               */
     double* var_pred;       /* (N+1, d, p, p, B)                                                            */
     /* rk_solve_sim: the sample path; mean_state / var_state are then the filter workspace                  */

@@ -54,6 +54,7 @@ struct DenseArgs {
     int mode, n0;                              // dense_fwd_kernel: 0 = all steps (built-in linear ODE); 1, 2: see there
     unsigned long long seed, traj_offset;      // Philox stream of the draws (interrogate_chkrebtii, solve_sim)
     double* x;                                 // solve_sim: draws, batch-minor like the lane kernels: x[(n p + i) B + b]
+    double *mean_pred, *var_pred;              // RK_FLAG_STORE_PRED (_solve_filter): (B, N+1, p), (B, N+1, p, p), or null
 };
 
 constexpr int DT = 512, NWAVE = DT / 64;
@@ -1018,6 +1019,12 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
         // time 0: (ode_init, 0)   (solve.py:53-54, 114-121)
         for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
         for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
+        if (a.mean_pred) {                               // index 0 of the predictions = (ode_init, 0) too (solve.py:114-121)
+            double* mp0 = a.mean_pred + (size_t)b * (a.N + 1) * p;
+            double* vp0 = a.var_pred + (size_t)b * (a.N + 1) * p * p;
+            for (int i = threadIdx.x; i < p; i += DT) mp0[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
+            for (int e = threadIdx.x; e < p * p; e += DT) vp0[e] = 0.0;
+        }
     }
     __syncthreads();
     // The step's dense products are issued from ONE wg_gemm call in a descriptor loop over its phases:
@@ -1043,6 +1050,13 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                 case 2:
                     if (q_bd) wg_bd_matvec(qd, w.mup, mu, p, nd);
                     else wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
+                    if (a.mean_pred) {                   // state_pred of the reference's _solve_filter (solve.py:99-104)
+                        __syncthreads();
+                        double* mpo = a.mean_pred + ((size_t)b * (a.N + 1) + n + 1) * p;
+                        double* vpo = a.var_pred + ((size_t)b * (a.N + 1) + n + 1) * p * p;
+                        for (int i = threadIdx.x; i < p; i += DT) mpo[i] = w.mup[i];
+                        for (int e = threadIdx.x; e < p * p; e += DT) vpo[e] = w.A2[e];
+                    }
                     if (a.itg == RK_INTERROGATE_CHKREBTII) {
                         // interrogate.py:22-34: the point the ODE is evaluated at, x ~ N(mu-, Sigma-), into w.dm
                         __syncthreads();
@@ -1297,7 +1311,7 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
                c->n_bstate, c->n_bmeas);
     RK_REQUIRE(c->n_bstate <= 768, RK_ERR_UNSUPPORTED, "dense path: n_bstate = %d exceeds 768 (LDS staging of the GEMMs)", c->n_bstate);
     RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "dense path: kalman_type must be standard");
-    RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED), RK_ERR_UNSUPPORTED, "dense path: RK_FLAG_STORE_PRED is not available");
+    RK_REQUIRE(!(c->flags & RK_FLAG_BATCH_MINOR), RK_ERR_UNSUPPORTED, "dense path: its layout is trajectory-major (RK_FLAG_BATCH_MINOR)");
     RK_REQUIRE(!in->ode_weight_batched && !in->prior_weight_batched && !in->prior_var_batched, RK_ERR_UNSUPPORTED,
                "dense path: ode_weight and prior_pars must be shared by all trajectories");
     if (c->rhs_id == RK_RHS_LINEAR_DENSE)
@@ -1327,6 +1341,10 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
     a.ws = (double*)out->workspace; a.ws_stride = dense_ws_doubles(a.p, a.m);
     a.mode = 0; a.n0 = 0;
     a.seed = c->seed; a.traj_offset = c->traj_offset; a.x = out->x_state;
+    a.mean_pred = (c->flags & RK_FLAG_STORE_PRED) ? out->mean_pred : nullptr;         // trajectory-major like mean / var
+    a.var_pred = (c->flags & RK_FLAG_STORE_PRED) ? out->var_pred : nullptr;
+    RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED) || (out->mean_pred && out->var_pred), RK_ERR_INVALID,
+               "RK_FLAG_STORE_PRED needs out->mean_pred / var_pred");
     RK_REQUIRE(mode != RK_MODE_SIM || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");
     hipLaunchKernelGGL(dense_qcheck_kernel, dim3(1), dim3(256), 0, h->stream, a.Q, a.p, a.p / a.m, a.ws + a.ws_stride - 1);
     if (c->rhs_id == RK_RHS_LINEAR_DENSE) {

@@ -181,7 +181,10 @@ class SolvePlan:
         self.layout = lay
         self.mean_state, self.var_state = self._bufs[lay]
         if self._store_pred and self.mean_pred is None:
-            self.mean_pred, self.var_pred = dev.empty((N1, d, p, B)), dev.empty((N1, d, p, p, B))
+            if lay == _lib.LAYOUT_TRAJ_MAJOR:                                 # the dense path keeps the reference's own layout
+                self.mean_pred, self.var_pred = dev.empty((B, N1, d, p)), dev.empty((B, N1, d, p, p))
+            else:
+                self.mean_pred, self.var_pred = dev.empty((N1, d, p, B)), dev.empty((N1, d, p, p, B))
         if mode == _lib.MODE_SIM and self.x_state is None:
             self.x_state = dev.empty((N1, d, p, B))
         wsb = C.c_size_t(0)
@@ -242,6 +245,9 @@ class SolvePlan:
         return self._host(self.mean_state), self._host(self.var_state)
 
     def pred_host(self):
+        if self.layout == _lib.LAYOUT_TRAJ_MAJOR:
+            mean, var = self.mean_pred.to_host(), self.var_pred.to_host()
+            return (mean, var) if self.batched else (mean[0], var[0])
         return self._host(self.mean_pred), self._host(self.var_pred)
 
     def x_host(self):

@@ -357,3 +357,30 @@ def test_dense_traced_ode_fun_chkrebtii_and_solve_sim(ra):
     x = ra.solve_sim(6, s["fun"], *args, g, s["prior"], kc=s["kc"])
     xo = scan.solve_sim(6, s["o_ode"], *args, o, s["prior"], kc=s["kc"])
     assert np.max(np.abs(x - xo) / np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1e-3)) < 1e-6
+
+
+def test_dense_solve_filter_returns_the_predictions(ra):
+    """_solve_filter (solve.py:31-122: state_pred and state_filt, index 0 = (ode_init, 0) in both) on the dense path, for the
+    built-in linear right-hand side and a traced one."""
+    n_vars, n_deriv, N, B = 6, 3, 10, 3
+    t_max = N / 24.0
+    s = dense_problem(ra, n_vars, n_deriv, N, t_max, B=B)
+    out = ra.solve._solve_filter(None, ra.ode.linear_dense(n_vars, n_deriv), s["W"], s["x0"], 0.0, t_max, N,
+                                 ra.interrogate.interrogate_rodeo, *s["prior"], A=s["A"])
+    ref = scan.solve_filter(None, odes.make_linear_dense(s["A"], n_deriv), s["W"], s["x0"], 0.0, t_max, N,
+                            oi.interrogate_rodeo, *s["prior"])
+    r = _ring_problem(ra, 8, 3, N, N / 30.0, B)
+    out2 = ra.solve._solve_filter(None, r["fun"], r["W"], r["x0"], 0.0, N / 30.0, N, ra.interrogate.interrogate_rodeo,
+                                  *r["prior"], kc=r["kc"])
+    ref2 = scan.solve_filter(None, r["o_ode"], r["W"], r["x0"], 0.0, N / 30.0, N, oi.interrogate_rodeo, *r["prior"], kc=r["kc"])
+    for o, f, x0 in ((out, ref, s["x0"]), (out2, ref2, r["x0"])):
+        for k in ("state_pred", "state_filt"):
+            m, v = o[k]
+            mo, vo = f[k]
+            assert m.shape == mo.shape and v.shape == vo.shape
+            sm = np.maximum(np.max(np.abs(mo), axis=(0, 1, 2)), 1e-3)
+            assert np.max(np.abs(m - mo) / sm) < 1e-8, k
+            dv = np.sqrt(np.abs(np.einsum("bnkii->bnki", vo)).max(axis=(0, 1, 2)))
+            assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :] + 1e-300)) < 1e-6, k
+            np.testing.assert_array_equal(m[:, 0], x0)
+            assert np.all(v[:, 0] == 0)
