@@ -405,6 +405,11 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
     constexpr int P = 3;
     __shared__ __attribute__((aligned(16))) char lds_all[2 * SIM_BUF];
     __shared__ __attribute__((aligned(16))) char zones[3 * ZONE_BYTES];
+    // Q | R of the workgroup's four tiles, read by the producers where they are used instead of living in 36 registers
+    // across the ticks (the kernel had 257 registers, i.e. one workgroup per CU; capped at 256 it spilled two of them,
+    // and a spill reload waits for every outstanding LDS-DMA load)
+    constexpr int QR_STRIDE = 2 * 9 + 2;
+    __shared__ __attribute__((aligned(16))) double qr[4 * QR_STRIDE];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * TILE_DOUBLES;
@@ -423,8 +428,22 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
         if (tau >= n_tiles) tau = n_tiles - 1;
         const int b = tau / D, blk = tau - b * D;
         const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
-        double Q[P][P], R[P][P];
-        load_block_consts<P>(a, blk, b, Q, R);
+        if (p == 0 && s == 0) {
+            double Q0[P][P], R0[P][P];
+            load_block_consts<P>(a, blk, b, Q0, R0);
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int j = 0; j < P; ++j) { qr[g * QR_STRIDE + i * P + j] = Q0[i][j]; qr[g * QR_STRIDE + 9 + i * P + j] = R0[i][j]; }
+        }
+        __syncthreads();                                           // (matched by the consumer's first barrier)
+        const double* const my_qr = qr + g * QR_STRIDE;
+        auto load_q = [&](double (&Qv)[P][P]) {
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int j = 0; j < P; ++j) Qv[i][j] = my_qr[i * P + j];
+        };
         int woff[9], voff[3], voff1[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -471,14 +490,26 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
                         for (int j = 0; j < P; ++j) Sf[i][j] = buf[i * 4 + j];
                         mf[i] = buf[i * 4 + 3];
                     }
-                    predict_block<P>(Q, R, mf, Sf, mp, Sp);              // pred[n+1] from filt[n]   (standard.py:57-59)
+                    {
+                        double Q[P][P], R[P][P];
+                        load_q(Q);
+#pragma unroll
+                        for (int i = 0; i < P; ++i)
+#pragma unroll
+                            for (int j = 0; j < P; ++j) R[i][j] = my_qr[9 + i * P + j];
+                        predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
+                    }
                     const int n = a.N - ch1 * CHUNK - s;
                     normal_pair(a.seed, traj, (uint32_t)(n < 1 ? 1 : n), (uint32_t)blk, PURPOSE_SMOOTH, 0u, z[0], z[1]);
                 }
             } else if (ch2 >= 0 && ch2 % 3 == p) {
                 // ---- stage 2 of chunk ch2: T (standard.py:175), LU of Sigma- with the forward sweep, the third normal ----
                 if (ch2 < n_chunks) {
-                    mm_nt<P, P, P>(Sf, Q, T);
+                    {
+                        double Q[P][P];
+                        load_q(Q);
+                        mm_nt<P, P, P>(Sf, Q, T);
+                    }
 #pragma unroll
                     for (int i = 0; i < P; ++i)
 #pragma unroll
@@ -539,6 +570,7 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
             rvec1[k] = sim_vec_byte(k, g, 1, r) - k * 4 * SIM_ITEM;
         }
         double x = 0.0;
+        __syncthreads();                                            // Q | R of the tiles are in LDS
         __syncthreads();
         __syncthreads();
         __syncthreads();
