@@ -202,16 +202,20 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             const double Mp = MF(U, Qt, Rt);
             const double MpT = MF(Qt0, U, RtT);
             const double R0 = MF(E0, Mp, 0.0);              // row 0 of M- in every row: [Sigma-_00 .. | mu-_0]
-            const double Z0 = MF(MpT, Wr, 0.0);             // Sigma- W^T                          (standard.py:97)
+            double Z0 = MF(MpT, Wr, 0.0);                   // Sigma- W^T                          (standard.py:97)
             const double WS0 = MF(Wr, Mp, 0.0);             // [W Sigma- | W mu-]
+            asm("" : "+v"(Z0) : "v"(WS0));                  // (keeps the last MFMA behind this one: hipcc moved WS0 to the end of the step)
             double S = MF(Z0, Wr, 0.0);
             S = S + S;                                      // + var_meas = W Sigma- W^T            (interrogate.py:26-29)
-            const double v_own = fma(fast_sqrt_pos(quad_bcast0(R0)), zn, quad_bcast3(R0));
+            const double rS = fast_rcp_cubic(S);            // (ahead of the draw's chain, which is independent of it: -3 %)
+            double r0v = R0;
+            asm("" : "+v"(r0v) : "v"(rS));
+            const double v_own = fma(fast_sqrt_pos(quad_bcast0(r0v)), zn, quad_bcast3(r0v));
             const double v_oth = pair_other_quad_uniform(v_own);
             const double am = fma(fma(fma(ac3, v_own, 0.0), v_own, ac1), v_own, fma(aco, v_oth, ac0));     // mean_meas = -f(x, t)
             const double WS = fma(e3c, am, WS0);            // yhat = W mu- + a in column 3         (standard.py:93)
             const double PW = Z0 * WS;
-            M = fma(-PW, fast_rcp_cubic(S), Mp);            // standard.py:98-102
+            M = fma(-PW, rS, Mp);                           // standard.py:98-102
         }
         store_row(M);
         return;
