@@ -24,11 +24,12 @@ __device__ __forceinline__ double MF(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// (for controls that give EVERY lane a source -- quad_perm, row_ror, the mirrors: the move then has no `old` operand and
+// hipcc does not copy x first when x stays live: six v_mov per step of the Lorenz63 p = 4 kernel)
 template <int CTRL>
 __device__ __forceinline__ double dpp64(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 // DPP move restricted to the banks (= tiles g, 4 lanes each) in BANK_MASK; other lanes keep `old`
