@@ -35,6 +35,7 @@
 // ten trailing updates alone 3 MB), 2 GB over the 256 workgroups, far beyond the L2s; the rank-16 updates reach
 // 7 TB/s aggregate.  Next step would be an LU whose [Sigma^- | T^T] stays in registers (200 tiles over 8 waves).
 // Phase timing: build with -DRK_DENSE_STAMPS, run scripts/bench_configs.py c5 with RK_DENSE_STAMPS=1.
+#include <type_traits>
 #include "common.hpp"
 #include "linalg_small.hpp"
 #include "solve_args.hpp"
@@ -51,7 +52,7 @@ struct DenseArgs {
     double *mean, *var;                        // (B, N+1, p), (B, N+1, p, p)
     double* ws;                                // workspace, ws_stride doubles per trajectory
     size_t ws_stride;
-    int mode, n0;                              // dense_fwd_kernel: 0 = all steps (built-in linear ODE); 1, 2: see there
+    int n0;                                    // dense_fwd_kernel<2>: the step whose update it runs
     unsigned long long seed, traj_offset;      // Philox stream of the draws (interrogate_chkrebtii, solve_sim)
     double* x;                                 // solve_sim: draws, batch-minor like the lane kernels: x[(n p + i) B + b]
     double *mean_pred, *var_pred;              // RK_FLAG_STORE_PRED (_solve_filter): (B, N+1, p), (B, N+1, p, p), or null
@@ -1003,6 +1004,12 @@ __device__ __forceinline__ GemmOp gemm_op(double* C, int ldc, const double* A, i
 // ---------------------------------------------------------------------------------------------------------------
 // Forward pass.  The step's dense products are issued from ONE wg_gemm instance in a descriptor loop.
 // ---------------------------------------------------------------------------------------------------------------
+// MODE 0: the whole forward pass with the built-in linear right-hand side; MODE 1, 2: the pieces around the interrogation
+// kernel of a hiprtc right-hand side (dense_solve): 1 = time 0 and step 0 up to mu-, 2 = the update of step n0 and step
+// n0 + 1 up to mu-.  (A template parameter: with run-time phase bounds the fused pass lost 9 %.)
+// EXTRA: interrogate_chkrebtii's draw and RK_FLAG_STORE_PRED compiled in (kept out of the instance that config 5 times:
+// their mere presence cost it 9 % through register allocation around the calls).
+template <int MODE, bool EXTRA>
 __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
     double* const qd = g_qd;
     const int b = blockIdx.x, p = a.p, m = a.m;
@@ -1014,12 +1021,12 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
     const double* Aode = a.theta;
     if (q_bd) load_qd(qd, a.Q, p, nd);
     RK_STAMP_DECL(a.ws + a.ws_stride);
-    if (a.mode != 2) {
+    if (MODE != 2) {
         RK_STAMP_ZERO();
         // time 0: (ode_init, 0)   (solve.py:53-54, 114-121)
         for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
         for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
-        if (a.mean_pred) {                               // index 0 of the predictions = (ode_init, 0) too (solve.py:114-121)
+        if (EXTRA && a.mean_pred) {                      // index 0 of the predictions = (ode_init, 0) too (solve.py:114-121)
             double* mp0 = a.mean_pred + (size_t)b * (a.N + 1) * p;
             double* vp0 = a.var_pred + (size_t)b * (a.N + 1) * p * p;
             for (int i = threadIdx.x; i < p; i += DT) mp0[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
@@ -1030,12 +1037,13 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
     // The step's dense products are issued from ONE wg_gemm call in a descriptor loop over its phases:
     // 0-1 predict (standard.py:57-59), 2 mu-, 3 interrogation and W~ Sigma-, 4 S, 5 (Sigma- W~^T)^T (standard.py:93-97),
     // 6 the LU solve, the mean and Sigma- - K (W~ Sigma-) (standard.py:98-102).
-    auto phases = [&](int n, int ph_lo, int ph_hi) {
+    auto phases = [&](int n, auto ph_lo, auto ph_hi) {
         const double* mu = mean + (size_t)n * p;
         const double* Sig = var + (size_t)n * p * p;
         double* mu_o = mean + (size_t)(n + 1) * p;
         double* Sig_o = var + (size_t)(n + 1) * p * p;
-        for (int ph = ph_lo; ph < ph_hi; ++ph) {
+#pragma unroll 1
+        for (int ph = decltype(ph_lo)::value; ph < decltype(ph_hi)::value; ++ph) {       // (ONE wg_gemm call site: not unrolled)
             GemmOp g;
             bool run = true;
             switch (ph) {
@@ -1050,14 +1058,14 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                 case 2:
                     if (q_bd) wg_bd_matvec(qd, w.mup, mu, p, nd);
                     else wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
-                    if (a.mean_pred) {                   // state_pred of the reference's _solve_filter (solve.py:99-104)
+                    if (EXTRA && a.mean_pred) {          // state_pred of the reference's _solve_filter (solve.py:99-104)
                         __syncthreads();
                         double* mpo = a.mean_pred + ((size_t)b * (a.N + 1) + n + 1) * p;
                         double* vpo = a.var_pred + ((size_t)b * (a.N + 1) + n + 1) * p * p;
                         for (int i = threadIdx.x; i < p; i += DT) mpo[i] = w.mup[i];
                         for (int e = threadIdx.x; e < p * p; e += DT) vpo[e] = w.A2[e];
                     }
-                    if (a.itg == RK_INTERROGATE_CHKREBTII) {
+                    if (EXTRA && a.itg == RK_INTERROGATE_CHKREBTII) {
                         // interrogate.py:22-34: the point the ODE is evaluated at, x ~ N(mu-, Sigma-), into w.dm
                         __syncthreads();
                         wg_normals(a.seed, (unsigned)(a.traj_offset + (unsigned long long)b), (unsigned)n, PURPOSE_INTERROGATE, p, 0);
@@ -1069,8 +1077,8 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                     // ---- interrogation (interrogate.py): W~ = W - J in w.Wt, the offset a = -f (+ J mu- for kramer,
                     // interrogate.py:81-82) in w.f.  Built in: the linear ODE f = A x, x_v = X[v * nd]; a right-hand
                     // side that arrives through hiprtc has filled both from its own kernel between two launches of this
-                    // one (a.mode != 0, solve_dense_itg_kernels.hpp) ----
-                    if (a.mode == 0) {
+                    // one (MODE != 0, solve_dense_itg_kernels.hpp) ----
+                    if (MODE == 0) {
                         for (int e = threadIdx.x; e < m * p; e += DT) {
                             const int i = e / p, j = e % p;
                             double Jij = 0.0;
@@ -1087,8 +1095,8 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                     for (int i = threadIdx.x >> 6; i < m; i += DT / 64) {
                         const int lane = threadIdx.x & 63;
                         double s = 0.0, jm = 0.0, wm = 0.0;
-                        if (a.mode == 0) {
-                            const double* const xe = a.itg == RK_INTERROGATE_CHKREBTII ? w.dm : w.mup;     // where f is evaluated
+                        if (MODE == 0) {
+                            const double* const xe = EXTRA && a.itg == RK_INTERROGATE_CHKREBTII ? w.dm : w.mup;     // where f is evaluated
                             for (int v = lane; v < m; v += 64) {
                                 const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
                                 s = fma(Aiv, xe[(size_t)v * nd], s);
@@ -1096,14 +1104,14 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                         }
                         for (int j = lane; j < p; j += 64) {
                             const double wt = w.Wt[(size_t)i * p + j], mj = w.mup[j];
-                            if (a.mode == 0) jm = fma(a.W[(size_t)i * p + j] - wt, mj, jm);
+                            if (MODE == 0) jm = fma(a.W[(size_t)i * p + j] - wt, mj, jm);
                             wm = fma(wt, mj, wm);
                         }
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) {
                             s += __shfl_xor(s, off); jm += __shfl_xor(jm, off); wm += __shfl_xor(wm, off);
                         }
-                        const double am = a.mode != 0 ? w.f[i] : (a.itg == RK_INTERROGATE_KRAMER ? -s + jm : -s);
+                        const double am = MODE != 0 ? w.f[i] : (a.itg == RK_INTERROGATE_KRAMER ? -s + jm : -s);
                         if (lane == 0) w.yhat[i] = wm + am;
                     }
                     g = gemm_op(w.WS, p, w.Wt, p, false, w.A2, p, false, m, p, p, nullptr, 0, 0.0, 1.0);          // W~ Sigma-
@@ -1112,7 +1120,7 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                 case 4: g = gemm_op(w.S, m, w.WS, p, false, w.Wt, p, true, m, m, p, nullptr, 0, 0.0, 1.0); break;  // (W~ Sigma-) W~^T
                 case 5: g = gemm_op(w.X, p, w.Wt, p, false, w.A2, p, true, m, p, p, nullptr, 0, 0.0, 1.0); break;  // (Sigma- W~^T)^T
                 default:
-                    if (a.itg == RK_INTERROGATE_RODEO || a.itg == RK_INTERROGATE_CHKREBTII) {   // + var_meas = W Sigma- W^T (W~ = W; interrogate.py:110-113, 26-29)
+                    if (a.itg == RK_INTERROGATE_RODEO || (EXTRA && a.itg == RK_INTERROGATE_CHKREBTII)) {   // + var_meas = W Sigma- W^T (W~ = W; interrogate.py:110-113, 26-29)
                         for (int e = threadIdx.x; e < m * m; e += DT) w.S[e] = w.S[e] + w.S[e];
                         __syncthreads();
                     }
@@ -1129,16 +1137,16 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
             RK_STAMP(ph);
         }
     };
-    // mode 0: the whole forward pass with the built-in linear right-hand side; modes 1, 2: the pieces around the
-    // interrogation kernel of a hiprtc right-hand side (dense_solve): 1 = time 0 and step 0 up to mu-,
-    // 2 = the update of step n0 and step n0 + 1 up to mu-
-    if (a.mode == 0) {
-        for (int n = 0; n < a.N; ++n) phases(n, 0, 7);
-    } else if (a.mode == 1) {
-        phases(0, 0, 3);
+    using P0 = std::integral_constant<int, 0>;
+    using P3 = std::integral_constant<int, 3>;
+    using P7 = std::integral_constant<int, 7>;
+    if (MODE == 0) {
+        for (int n = 0; n < a.N; ++n) phases(n, P0{}, P7{});
+    } else if (MODE == 1) {
+        phases(0, P0{}, P3{});
     } else {
-        phases(a.n0, 3, 7);
-        if (a.n0 + 1 < a.N) phases(a.n0 + 1, 0, 3);
+        phases(a.n0, P3{}, P7{});
+        if (a.n0 + 1 < a.N) phases(a.n0 + 1, P0{}, P3{});
     }
 }
 
@@ -1339,7 +1347,7 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
     a.x0_b = in->ode_init_batched; a.theta_b = in->theta_batched;
     a.mean = out->mean_state; a.var = out->var_state;
     a.ws = (double*)out->workspace; a.ws_stride = dense_ws_doubles(a.p, a.m);
-    a.mode = 0; a.n0 = 0;
+    a.n0 = 0;
     a.seed = c->seed; a.traj_offset = c->traj_offset; a.x = out->x_state;
     a.mean_pred = (c->flags & RK_FLAG_STORE_PRED) ? out->mean_pred : nullptr;         // trajectory-major like mean / var
     a.var_pred = (c->flags & RK_FLAG_STORE_PRED) ? out->var_pred : nullptr;
@@ -1347,9 +1355,11 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
                "RK_FLAG_STORE_PRED needs out->mean_pred / var_pred");
     RK_REQUIRE(mode != RK_MODE_SIM || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");
     hipLaunchKernelGGL(dense_qcheck_kernel, dim3(1), dim3(256), 0, h->stream, a.Q, a.p, a.p / a.m, a.ws + a.ws_stride - 1);
+    const bool extra = c->interrogate == RK_INTERROGATE_CHKREBTII || (c->flags & RK_FLAG_STORE_PRED);
     if (c->rhs_id == RK_RHS_LINEAR_DENSE) {
         LaunchTimer t(h, "dense_fwd_kernel");
-        hipLaunchKernelGGL(dense_fwd_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+        if (extra) hipLaunchKernelGGL((dense_fwd_kernel<0, true>), dim3(a.B), dim3(DT), 0, h->stream, a);
+        else hipLaunchKernelGGL((dense_fwd_kernel<0, false>), dim3(a.B), dim3(DT), 0, h->stream, a);
         t.stop();
     } else {
         // a right-hand side built by hiprtc: the step is cut at the interrogation (solve_dense_itg_kernels.hpp) -- the
@@ -1364,15 +1374,13 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
             g.off_x = c->interrogate == RK_INTERROGATE_CHKREBTII ? g.off_mup + a.p + 2 * (size_t)a.m : g.off_mup;    // w.dm / w.mup
         }
         LaunchTimer t(h, "dense_fwd_kernel<user, stepwise>");
-        a.mode = 1;
-        hipLaunchKernelGGL(dense_fwd_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
-        a.mode = 2;
+        hipLaunchKernelGGL((dense_fwd_kernel<1, true>), dim3(a.B), dim3(DT), 0, h->stream, a);
         for (int n = 0; n < a.N; ++n) {
             g.n = n;
             const int rc = user_dense_interrogate(h, c, g);
             if (rc) return rc;
             a.n0 = n;
-            hipLaunchKernelGGL(dense_fwd_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+            hipLaunchKernelGGL((dense_fwd_kernel<2, true>), dim3(a.B), dim3(DT), 0, h->stream, a);
         }
         t.stop();
     }

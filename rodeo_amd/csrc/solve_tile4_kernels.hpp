@@ -76,12 +76,9 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
         // (the state of time n is stored one step late, behind the first MFMA of step n + 1: solve_tile3_kernels.hpp)
         for (int n = 0; n < a.N; ++n) {
             const double U = MF(S, Qt, 0.0);
-            {
-                double vS = S, vM = m;
-                asm("" : "+v"(vS), "+v"(vM) : "v"(U));
-                store_row(vS, vM);
-                row += tstride_all * sizeof(double);
-            }
+            asm volatile("" :: "v"(U) : "memory");                   // (the stores stay behind U; no copy of m, which lives on)
+            store_row(S, m);
+            row += tstride_all * sizeof(double);
             const double v_own = MF(Y0, m, 0.0);                      // (Q mu)_0 in all 16 lanes of the tile
             const double mp = MF(Qt, m, 0.0);                         // Q mu, row form
             const double SpT = MF(Qt, U, RtT);                        // exact transpose of S-: Q Sigma^T Q^T + R^T
@@ -105,13 +102,10 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
     const size_t sS = tc.valid ? tstride_all : 0, sM = st_m ? tstride_all : 0;
     for (int n = 0; n < a.N; ++n) {
         const double U = MF(S, Qt, 0.0);
-        {
-            double vS = S, vM = m;
-            asm("" : "+v"(vS), "+v"(vM) : "v"(U));
-            oS[0] = vS;
-            oM[0] = vM;
-            oS += sS; oM += sM;
-        }
+        asm volatile("" :: "v"(U) : "memory");
+        oS[0] = S;
+        oM[0] = m;
+        oS += sS; oM += sM;
         const double v_own = MF(Y0, m, 0.0);                      // (Q mu)_0 in all 16 lanes of the tile
         const double mp = MF(Qt, m, 0.0);                         // Q mu, row form
         const double Sp = MF(U, Qt, Rt);                          // Q Sigma Q^T + R

@@ -147,12 +147,12 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
             offS[k][bb] = (valid && i < P && j < P) ? (int)((g * PP + i * P + j) * sizeof(double)) : (int)0x80000000;
         }
     }
-    // (called one step late, behind the first MFMAs of the next step -- `after` is one of their results, which the
-    // stored copies are made to "depend" on with an empty asm: solve_tile3_kernels.hpp, store_behind)
+    // (called one step late, behind the first MFMAs of the next step -- `after` is one of their results: an empty asm
+    // that reads it and clobbers memory keeps the stores behind it; solve_tile3_kernels.hpp, RK_STORE_BEHIND)
     auto store = [&](double after) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, TPW * PP * 8, 0x00020000);
+        asm volatile("" :: "v"(after) : "memory");               // (the stores stay behind that MFMA; no copies of the state)
         auto put = [&](double v, int off) {
-            asm("" : "+v"(v) : "v"(after));
             u32x2 bits;
             __builtin_memcpy(&bits, &v, 8);
             __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, off, 0, 0);

@@ -27,7 +27,7 @@ def c3(args):
     x0 = init(np.array([-12., -5., 38.]) + 1e-3 * rng.standard_normal((B, 3)), 0.0, theta=theta)
     prior = ra.ibm_init(20.0 / N, p, np.array([5e7] * 3))
     plan = ra.SolvePlan(ra.ode.lorenz63, W, x0, 0.0, 20.0, N, ra.interrogate.interrogate_kramer, prior, theta=theta)
-    ms = timeit(lambda: plan.mv(None), plan.dev, 2)
+    ms = timeit(lambda: plan.mv(None), plan.dev, 5)
     a = 3 * 3 * p * (p + 1) * 8
     plan.dev.profile_enable(True)
     plan.mv(None); plan.dev.sync()
