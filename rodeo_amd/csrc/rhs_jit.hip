@@ -61,8 +61,10 @@ static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<c
     }
     const std::string expr = kernel_expr(u, P, itg, kind);
     hiprtcAddNameExpression(prog, expr.c_str());
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-falign-loops=64"};     // (Makefile: why aligned loops)
-    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    // (Makefile: why aligned loops; MFMA results in VGPRs like the ahead-of-time build -- without it every MFMA result of the
+    // tile kernels went through an AGPR and two v_accvgpr_read, 12 extra instructions per step of the p = 3 forward kernel)
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-falign-loops=64", "-mllvm", "-amdgpu-mfma-vgpr-form"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
