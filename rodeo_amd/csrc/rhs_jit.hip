@@ -6,8 +6,11 @@
 // rk::AutoJac of csrc/dual.hpp for the Jacobian) and the kernel templates of solve_small_kernels.hpp are
 // instantiated for it at run time, once per (n_bstate, interrogation) actually used.
 #include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <limits.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -30,6 +33,20 @@ static std::mutex g_mu;
 static std::vector<UserRhs> g_rhs;                                   // id = RK_RHS_USER_BASE + index
 struct JitEntry { hipModule_t mod; hipFunction_t fn; };
 static std::map<std::tuple<int, int, int, int, int>, JitEntry> g_cache;   // (device, rhs, P, itg, kind)
+
+// Is the libhiprtc behind hiprtcCompileProgram the one under /opt/rocm (the toolchain of this build)?  RK_JIT_BACKEND_OPTIONS
+// = 0 / 1 overrides.
+static bool hiprtc_takes_backend_options() {
+    static const int v = [] {
+        if (const char* e = getenv("RK_JIT_BACKEND_OPTIONS")) return atoi(e) != 0 ? 1 : 0;
+        Dl_info info;
+        if (!dladdr((void*)&hiprtcCompileProgram, &info) || !info.dli_fname) return 0;
+        char real[PATH_MAX];
+        const char* path = realpath(info.dli_fname, real) ? real : info.dli_fname;
+        return strncmp(path, "/opt/rocm", 9) == 0 ? 1 : 0;
+    }();
+    return v != 0;
+}
 
 static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
     char buf[512];
@@ -62,9 +79,13 @@ static int jit_compile(const UserRhs& u, int P, int itg, int kind, std::vector<c
     const std::string expr = kernel_expr(u, P, itg, kind);
     hiprtcAddNameExpression(prog, expr.c_str());
     // (Makefile: why aligned loops; MFMA results in VGPRs like the ahead-of-time build -- without it every MFMA result of the
-    // tile kernels went through an AGPR and two v_accvgpr_read, 12 extra instructions per step of the p = 3 forward kernel)
+    // tile kernels goes through an AGPR and two v_accvgpr_read, 12 extra instructions per step of the p = 3 forward kernel:
+    // 0.79 against 0.67 ms on the headline shape.)  The -mllvm option exists in the ROCm compiler this library was built
+    // with; an unknown -mllvm option makes LLVM call exit(), and in a process that loaded another ROCm first (import torch:
+    // its wheel carries its own libhiprtc / comgr under the same soname) the calls below land in THAT one -- so the
+    // option is passed only when the hiprtc that serves us is the system's.
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-falign-loops=64", "-mllvm", "-amdgpu-mfma-vgpr-form"};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
+    const hiprtcResult r = hiprtcCompileProgram(prog, hiprtc_takes_backend_options() ? 6 : 4, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);

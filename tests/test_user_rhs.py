@@ -121,6 +121,24 @@ def test_non_block_form_beyond_the_lane_kernels_builds_the_dense_interrogation_k
         trace.trace_source(lambda X, t: np.array([[X[0, 0]] * 5, [X[1, 0]] * 5]), 2, 2, (), "FiveMeasurementsTwoBlocks")
 
 
+def test_run_time_builds_survive_another_rocm_in_the_process():
+    """A process that imported torch first carries torch's own libhiprtc / comgr under the same soname, and the library's
+    hiprtc calls land there; an -mllvm option that compiler does not know makes LLVM call exit() (found when the GPU suite
+    died without a message in its first traced test).  The option is therefore only passed to the system's hiprtc
+    (rhs_jit.hip, hiprtc_takes_backend_options); here: the build goes through in a child process with torch loaded."""
+    import os, subprocess, sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import torch, sys, numpy as np; sys.path.insert(0, %r); import rodeo_amd as ra\n"
+        "def f(X, t, theta):\n"
+        "    return np.array([[theta[0] * X[0, 0] - X[1, 0] ** 2], [np.sin(X[0, 0]) + theta[1]]])\n"
+        "ra.ode.compile_check(ra.ode.from_python(f, 2, theta=2), 3)\n"
+        "print('built')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "built" in out.stdout, out.stderr[-2000:]
+
+
 def test_first_order_pad_with_plain_python_function_is_batch_safe():
     """utils.first_order_pad on the reference's own kind of ode_fun (written for one trajectory): a batch of initial
     values and parameters is evaluated per element, and equals the built-in functor's initialisation."""
