@@ -56,7 +56,17 @@ def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10
             d_up = cache["up"] = dev.to_device(upt)
         else:
             d_up.upload(upt)
-    out = dev.empty((plan.B,))
+    # the result buffer comes from a small ring on the plan (a device allocation per call cost more than the kernel: 0.08 of
+    # C4's 0.32 ms per evaluation); a returned array is overwritten by the FOURTH call after it
+    ring = cache.setdefault("out_ring", [])
+    if len(ring) < 4 or tuple(ring[0].shape) != (plan.B,):
+        if ring and tuple(ring[0].shape) != (plan.B,):
+            ring.clear()
+        ring.append(dev.empty((plan.B,)))
+        out = ring[-1]
+    else:
+        cache["out_next"] = (cache.get("out_next", 0) + 1) % 4
+        out = ring[cache["out_next"]]
     _lib.check(dev.lib.rk_gauss_obs_logpost(dev.h, plan.B, plan.N, plan.d, plan.p, layout, state.ptr, d_obs.ptr,
                                             d_ind.ptr, ind.shape[0], float(noise_sd),
                                             d_up.ptr if d_up is not None else None, k, float(prior_sd), out.ptr))
