@@ -562,6 +562,8 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
         const size_t xstride = (size_t)D * P * a.B;
         double* bx = st ? a.x + ((size_t)blk * P + r) * a.B + b : dump + lane;
         const size_t sx = st ? xstride : 0;
+        const bool xbuf_ok = (size_t)CHUNK * xstride * sizeof(double) < 0x7fffffffull;
+        const int xvo = st && xbuf_ok ? (int)((((size_t)blk * P + r) * a.B + b) * sizeof(double)) : (int)0x80000000;
         int roff[4], rvec[4], rvec1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -585,7 +587,22 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
                 o[0] = x;
                 o -= sx;
             };
-            if (cnt == CHUNK) {
+            if (cnt == CHUNK && xbuf_ok) {
+                // whole chunk: the draws leave through a buffer window on the chunk's 16 time rows of x (scalar base,
+                // constant per-lane offset, lanes without a slot out of range) -- no 64-bit pointer arithmetic on the chain
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(a.x + (size_t)(n_hi - (CHUNK - 1)) * xstride), 0, (int)(CHUNK * xstride * sizeof(double)), 0x00020000);
+#pragma unroll
+                for (int s = 0; s < CHUNK; ++s) {
+                    const double Gt = *(const double*)(in + roff[s & 3] + s * 4 * SIM_ITEM);
+                    const double mp = *(const double*)(in + rvec[s & 3] + s * 4 * SIM_ITEM);
+                    const double mfw = *(const double*)(in + rvec1[s & 3] + s * 4 * SIM_ITEM);
+                    x = MF(Gt, x - mp, mfw);
+                    u32x2 bits;
+                    __builtin_memcpy(&bits, &x, 8);
+                    __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, xvo, (int)((CHUNK - 1 - s) * xstride * sizeof(double)), 0);
+                }
+            } else if (cnt == CHUNK) {
 #pragma unroll
                 for (int s = 0; s < CHUNK; ++s) step(in + roff[s & 3] + s * 4 * SIM_ITEM, in + rvec[s & 3] + s * 4 * SIM_ITEM,
                                                      in + rvec1[s & 3] + s * 4 * SIM_ITEM);
