@@ -294,11 +294,23 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
                     if (s + LOOKAHEAD < CH4) load(s + LOOKAHEAD);
                     __builtin_amdgcn_sched_barrier(0);
                     const double V1 = MF(Ss - Sp[s], Gt[s], 0.0);       // (G D)^T
+                    if constexpr (TPW == 4) {
+                        // four tiles per wave: the previous step's results go into the image here, a step old and behind
+                        // an MFMA (profiles/r02_probe13_store_cost.log); measured -5 % with four tiles, +4 % with three
+                        if (s >= 1) {
+                            double So = Ss, mo = ms;
+                            asm("" : "+v"(So), "+v"(mo) : "v"(V1));
+                            if (tc.valid) *(double*)(img + (s - 1) * TPW * ITEM4 + wS) = So;
+                            if (st_m) *(double*)(img + (s - 1) * TPW * ITEM4 + wM) = mo;
+                        }
+                    }
                     ms = MF(Gt[s], ms - mp[s], mf[s]);                  // mu_f + G (mu_s - mu-)     (standard.py:213-214)
                     Ss = MF(V1, Gt[s], Sf[s]);                          // Sigma_f + G D G^T         (standard.py:215-216)
-                    if (tc.valid) *(double*)(img + s * TPW * ITEM4 + wS) = Ss;      // (exec-masked: measured faster than
-                    if (st_m) *(double*)(img + s * TPW * ITEM4 + wM) = ms;          // sending idle lanes to a dump slot)
-                    if ((s + 1) % RPF == 0 && self_flush) {
+                    if (TPW != 4 || s == CH4 - 1) {
+                        if (tc.valid) *(double*)(img + s * TPW * ITEM4 + wS) = Ss;  // (exec-masked: measured faster than
+                        if (st_m) *(double*)(img + s * TPW * ITEM4 + wM) = ms;      // sending idle lanes to a dump slot)
+                    }
+                    if (TPW != 4 && (s + 1) % RPF == 0 && self_flush) {
                         const int k = s / RPF;
                         fl[k] = *(const u32x4*)(img + (s - (RPF - 1)) * TPW * ITEM4 + f_lds);
                         if (k >= 1)
@@ -306,7 +318,17 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (self_flush) __builtin_amdgcn_raw_buffer_store_b128(fl[NFL - 1], rsrc, f_vo, 0, 0);
+                if (self_flush) {
+                    if constexpr (TPW == 4) {                       // (rows are complete only now: their writes run a step late)
+#pragma unroll
+                        for (int k = 0; k < NFL; ++k) {
+                            const u32x4 v = *(const u32x4*)(img + k * RPF * TPW * ITEM4 + f_lds);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, f_vo, (int)((CH4 - (k + 1) * RPF) * row_bytes), 0);
+                        }
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(fl[NFL - 1], rsrc, f_vo, 0, 0);
+                    }
+                }
             } else {
                 for (int s = 0; s < cnt; ++s) {
                     const char* q = in + lds4_tile<TPW>(s, gl, 0, idx);
