@@ -10,6 +10,7 @@
 // HBM format (RK_LAYOUT_TILE4): per time step and (trajectory, block) 20 doubles [Sigma row-major (16) | mu (4)]
 // = 160 B = the algorithmic p (p + 1) 8 bytes.  With n_block = 3 a wave carries the three blocks of ONE trajectory in
 // tiles g = 0..2 (g = 3 idles); with n_block = 2 two trajectories; with n_block = 1 four.
+#include <algorithm>
 #include "common.hpp"
 #include "kalman_small.hpp"
 #include "mfma_tile.hpp"
@@ -348,6 +349,9 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
             __syncthreads();
             const long long tC = T4_NOW();
             cacc[0] += tB - tA; cacc[1] += tC - tB;
+#if RK_T4_STAMPS >= 3      // per-tick consumer work of the first 8 workgroups, behind the per-workgroup sums
+            if (blockIdx.x < 8 && t < 2048 && lane == 0) dbg[(size_t)gridDim.x * 20 + (size_t)blockIdx.x * 2048 + t] = tB - tA;
+#endif
 #else
             __syncthreads();
 #endif
@@ -417,8 +421,8 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     LaunchTimer t(h, "bwd_mv_tile4_kernel");
 #ifdef RK_T4_STAMPS
     long long* dbg = nullptr;
-    RK_HIP(hipMalloc(&dbg, (size_t)grid.x * 20 * sizeof(long long)));
-    RK_HIP(hipMemsetAsync(dbg, 0, (size_t)grid.x * 20 * sizeof(long long), h->stream));
+    RK_HIP(hipMalloc(&dbg, ((size_t)grid.x * 20 + 8 * 2048) * sizeof(long long)));
+    RK_HIP(hipMemsetAsync(dbg, 0, ((size_t)grid.x * 20 + 8 * 2048) * sizeof(long long), h->stream));
 #define T4_DBG , dbg
 #else
 #define T4_DBG
@@ -431,7 +435,7 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     RK_HIP(hipGetLastError());
 #ifdef RK_T4_STAMPS
     {
-        std::vector<long long> hd((size_t)grid.x * 20);
+        std::vector<long long> hd((size_t)grid.x * 20 + 8 * 2048);
         RK_HIP(hipMemcpyAsync(hd.data(), dbg, hd.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
         RK_HIP(hipStreamSynchronize(h->stream));
         RK_HIP(hipFree(dbg));
@@ -459,6 +463,17 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
         fprintf(stderr, "[t4 stamps] kernel span %.1f us (100 MHz clock), mean workgroup lifetime %.1f us; workgroups per (xcc, se, cu): ", (t_max - t_min) / 100.0, life / 100.0);
         for (int k = 1; k < 8; ++k) if (hist[k]) fprintf(stderr, "%d CUs with %d, ", hist[k], k);
         fprintf(stderr, "consumer waves of a CU on the same SIMD: %d of %d pairs", same_simd, pairs);
+#if RK_T4_STAMPS >= 3
+        for (int w8 = 0; w8 < 8 && w8 < (int)grid.x; ++w8) {
+            std::vector<long long> v;
+            for (int t = 0; t < 2048; ++t) if (hd[(size_t)grid.x * 20 + w8 * 2048 + t] > 0) v.push_back(hd[(size_t)grid.x * 20 + w8 * 2048 + t]);
+            if (v.empty()) continue;
+            std::vector<long long> q = v; std::sort(q.begin(), q.end());
+            fprintf(stderr, "\n[t4 stamps] workgroup %d consumer work per tick: min %lld p10 %lld p50 %lld p90 %lld max %lld; first ticks:", w8,
+                    q.front(), q[q.size() / 10], q[q.size() / 2], q[q.size() * 9 / 10], q.back());
+            for (int t = 100; t < 124 && t < (int)v.size(); ++t) fprintf(stderr, " %lld", v[t]);
+        }
+#endif
         fprintf(stderr, "\n");
     }
 #endif
