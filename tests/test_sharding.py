@@ -7,8 +7,12 @@ import os
 import socket
 import numpy as np
 import pytest
-import torch.multiprocessing as mp
 from rodeo_amd import shard as rs
+
+# torch (its gloo backend) is imported only inside the tests that use it: a module-level import would load the wheel's own ROCm
+# runtime into every pytest process that merely COLLECTS this file -- including the `-m gpu` run, whose kernels and
+# run-time builds would then go through that runtime instead of the system's (tests/test_user_rhs.py,
+# test_run_time_builds_survive_another_rocm_in_the_process).
 
 
 def test_partition_covers_everything():
@@ -61,6 +65,7 @@ def _free_port():
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_equals_single_process(world):
+    import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
