@@ -7,6 +7,7 @@
 // instantiated for it at run time, once per (n_bstate, interrogation) actually used.
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <link.h>
 #include <limits.h>
 #include <cstdio>
 #include <cstdlib>
@@ -34,16 +35,37 @@ static std::vector<UserRhs> g_rhs;                                   // id = RK_
 struct JitEntry { hipModule_t mod; hipFunction_t fn; };
 static std::map<std::tuple<int, int, int, int, int>, JitEntry> g_cache;   // (device, rhs, P, itg, kind)
 
-// Is the libhiprtc behind hiprtcCompileProgram the one under /opt/rocm (the toolchain of this build)?  RK_JIT_BACKEND_OPTIONS
-// = 0 / 1 overrides.
+// Are BOTH the libhiprtc behind hiprtcCompileProgram and the compiler library it drives (libamd_comgr) the ones under
+// /opt/rocm (the toolchain of this build)?  Evaluated at the first compilation, i.e. after whatever the process has loaded
+// by then: torch imported BEFORE this library brings its own libhiprtc, torch imported AFTER it (but before the first
+// build) its own libamd_comgr, which the system's hiprtc then picks up -- either way the option must stay away.
+// RK_JIT_BACKEND_OPTIONS = 0 / 1 overrides.
+static bool under_opt_rocm(const char* path) {
+    char real[PATH_MAX];
+    const char* r = path && realpath(path, real) ? real : path;
+    return r && strncmp(r, "/opt/rocm", 9) == 0;
+}
+static int find_comgr(struct dl_phdr_info* info, size_t, void* out) {
+    if (info->dlpi_name && strstr(info->dlpi_name, "libamd_comgr")) {
+        *(std::string*)out = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
 static bool hiprtc_takes_backend_options() {
     static const int v = [] {
         if (const char* e = getenv("RK_JIT_BACKEND_OPTIONS")) return atoi(e) != 0 ? 1 : 0;
         Dl_info info;
-        if (!dladdr((void*)&hiprtcCompileProgram, &info) || !info.dli_fname) return 0;
-        char real[PATH_MAX];
-        const char* path = realpath(info.dli_fname, real) ? real : info.dli_fname;
-        return strncmp(path, "/opt/rocm", 9) == 0 ? 1 : 0;
+        if (!dladdr((void*)&hiprtcCompileProgram, &info) || !under_opt_rocm(info.dli_fname)) return 0;
+        std::string comgr;
+        dl_iterate_phdr(find_comgr, &comgr);
+        if (comgr.empty()) {                              // not loaded yet: take the one next to this hiprtc, now
+            std::string dir(info.dli_fname);
+            dir.erase(dir.find_last_of('/') + 1);
+            if (!dlopen((dir + "libamd_comgr.so.3").c_str(), RTLD_NOW | RTLD_GLOBAL)) return 0;
+            dl_iterate_phdr(find_comgr, &comgr);
+        }
+        return !comgr.empty() && under_opt_rocm(comgr.c_str()) ? 1 : 0;
     }();
     return v != 0;
 }

@@ -129,14 +129,18 @@ def test_run_time_builds_survive_another_rocm_in_the_process():
     import os, subprocess, sys
     pytest.importorskip("torch")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import torch, sys, numpy as np; sys.path.insert(0, %r); import rodeo_amd as ra\n"
-        "def f(X, t, theta):\n"
-        "    return np.array([[theta[0] * X[0, 0] - X[1, 0] ** 2], [np.sin(X[0, 0]) + theta[1]]])\n"
-        "ra.ode.compile_check(ra.ode.from_python(f, 2, theta=2), 3)\n"
-        "print('built')\n" % root)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "built" in out.stdout, out.stderr[-2000:]
+    body = ("def f(X, t, theta):\n"
+            "    return np.array([[theta[0] * X[0, 0] - X[1, 0] ** 2], [np.sin(X[0, 0]) + theta[1]]])\n"
+            "ra.ode.compile_check(ra.ode.from_python(f, 2, theta=2), 3)\n"
+            "print('built')\n")
+    # torch before the library (its libhiprtc serves the calls), and the library before torch (the system's libhiprtc, but
+    # torch's libamd_comgr is in the process by the time of the first build): the second order is what killed the CPU
+    # suite once the gloo tests imported torch lazily
+    orders = ("import torch, sys, numpy as np; sys.path.insert(0, %r); import rodeo_amd as ra\n" % root,
+              "import sys, numpy as np; sys.path.insert(0, %r); import rodeo_amd as ra; ra._lib.load(); import torch\n" % root)
+    for head in orders:
+        out = subprocess.run([sys.executable, "-c", head + body], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "built" in out.stdout, (head, out.stderr[-2000:])
 
 
 def test_first_order_pad_with_plain_python_function_is_batch_safe():
