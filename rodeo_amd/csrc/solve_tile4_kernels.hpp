@@ -97,6 +97,52 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
         store_row(S, m);
         return;
     }
+    if constexpr (rhs_has_tile_form<RHS>::value && D == 2) {
+        // Right-hand sides with the two-block tile form of the p = 3 kernel (FitzHugh-Nagumo: f and J0 of a block are
+        // polynomials in its own and the other block's evaluation point, RHS::tile_eval) without the generic path's
+        // gathers, block arrays and selects: the other block's point by one row_half_mirror move, per-lane coefficients,
+        // buffer stores with a scalar row base.  Same arithmetic as the generic path below.
+        double tk[RHS::NTILEK];
+        RHS::tile_consts(blk, th, tk);
+        const char* row = (const char*)(tiles + (size_t)blockIdx.x * Tpw<D>::value * T4_DOUBLES);
+        const int voS = tc.valid ? (int)((tc.g * T4_DOUBLES + r * 4 + c) * sizeof(double)) : (int)0x80000000;
+        const int voM = st_m ? (int)((tc.g * T4_DOUBLES + 16 + r) * sizeof(double)) : (int)0x80000000;
+        auto store_row = [&](double vS, double vM) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, Tpw<D>::value * T4_DOUBLES * 8, 0x00020000);
+            u32x2 bS, bM;
+            __builtin_memcpy(&bS, &vS, 8);
+            __builtin_memcpy(&bM, &vM, 8);
+            __builtin_amdgcn_raw_buffer_store_b64(bS, rsrc, voS, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(bM, rsrc, voM, 0, 0);
+        };
+        for (int n = 0; n < a.N; ++n) {
+            const double U = MF(S, Qt, 0.0);
+            asm volatile("" :: "v"(U) : "memory");                   // (the state of time n leaves behind U: solve_tile3_kernels.hpp)
+            store_row(S, m);
+            row += tstride_all * sizeof(double);
+            const double v_own = MF(Y0, m, 0.0);                      // (Q mu)_0 in all 16 lanes of the tile
+            const double mp = MF(Qt, m, 0.0);                         // Q mu, row form
+            const double Sp = MF(U, Qt, Rt);                          // Q Sigma Q^T + R
+            const double SpT = MF(Qt, U, RtT);                        // its exact transpose
+            const double v_oth = pair_other_quad_uniform(v_own);      // the other block's evaluation point
+            const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
+            double fb, J0;
+            RHS::tile_eval(tk, v_own, v_oth, t, fb, J0);
+            if constexpr (ITG != RK_INTERROGATE_KRAMER) J0 = 0.0;
+            const double a_meas = fma(J0, v_own, -fb);                // mean_meas = -f + J mu-   (interrogate.py:81-82)
+            const double Xw = fma(-J0, E0, Wr);                       // W~ = W - J, row form     (solve.py:79)
+            const double yhat = MF(Xw, mp, a_meas);
+            const double WS = MF(Xw, Sp, 0.0);
+            const double Z = MF(SpT, Xw, 0.0);                        // Sigma- W~^T (standard.py:97), row form
+            double Sc = MF(Z, Xw, 0.0);
+            if constexpr (ITG == RK_INTERROGATE_RODEO) Sc = Sc + Sc;  // var_meas = W Sigma- W^T (interrogate.py:110-113)
+            const double K = Z * fast_rcp_cubic(Sc);
+            S = fma(-K, WS, Sp);
+            m = fma(-K, yhat, mp);
+        }
+        store_row(S, m);
+        return;
+    }
     double* oS = tc.valid ? tiles + (size_t)tc.tau * T4_DOUBLES + r * 4 + c : dump + threadIdx.x;
     double* oM = st_m ? tiles + (size_t)tc.tau * T4_DOUBLES + 16 + r : dump + 64 + threadIdx.x;
     const size_t sS = tc.valid ? tstride_all : 0, sM = st_m ? tstride_all : 0;
