@@ -165,6 +165,8 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
         }
     };
 
+    double tk[tile_form_consts<RHS>::N];
+    if constexpr (rhs_has_tile_form<RHS>::value && D == 2) RHS::tile_consts(blk, th, tk);
     for (int n = 0; n < a.N; ++n) {
         if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
             if ((n & 15) == 0) {                          // the 16 lanes of a unit draw z_0 for 16 consecutive steps
@@ -192,6 +194,13 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
             v_own = fma(sqrt(s00 > 0.0 ? s00 : 0.0), zn, v_own);
         }
         // ---- interrogation (interrogate.py): f and the block-diagonal Jacobian entry at the evaluation points ----
+        const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
+        double fb, J0;
+        if constexpr (rhs_has_tile_form<RHS>::value && D == 2 && NW == 1) {
+            // two-block tile form (FitzHugh-Nagumo): the other block's point by one DPP move, per-lane coefficients
+            RHS::tile_eval(tk, v_own, pair_other_quad_uniform(v_own), t, fb, J0);
+            if constexpr (ITG != RK_INTERROGATE_KRAMER) J0 = 0.0;
+        } else {
         double X[D][1];
         if constexpr (NW == 1) {
             double vals[D];
@@ -204,8 +213,6 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
 #pragma unroll
             for (int bb = 0; bb < D; ++bb) X[bb][0] = vx[n & 1][bb];
         }
-        const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;     // solve.py:74
-        double fb, J0;
         if constexpr (ITG == RK_INTERROGATE_KRAMER && rhs_has_fjac0<RHS>::value) {
             RHS::template fjac0_block<1>(X, t, th, blk, fb, J0);
         } else {
@@ -221,6 +228,7 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
 #pragma unroll
             for (int bb = 0; bb < D; ++bb) J0s[bb] = J[bb][0];
             fb = pick_block<D>(f, blk); J0 = pick_block<D>(J0s, blk);
+        }
         }
         // kramer: mean_meas = -f + J mu- (interrogate.py:81-82; J has only its first entry); the others: -f(x)
         const double a_meas = ITG == RK_INTERROGATE_KRAMER ? fma(J0, v_own, -fb) : -fb;
