@@ -77,18 +77,17 @@ __device__ __forceinline__ void gather_blocks(double own, double (&vals)[D]) {
     } else if constexpr (D == 2) {
         vals[0] = pair_block0(own);
         vals[1] = pair_block1(own);
-    } else if constexpr (D == 3) {
-        // tiles g = 0, 1, 2 are blocks 0, 1, 2;  ror:4k moves a value k tiles up
-        vals[0] = dpp64_banks<0x128, 0x4>(dpp64_banks<0x124, 0x2>(own, own), own);   // g=1 <- g-1, g=2 <- g-2
-        vals[1] = dpp64_banks<0x124, 0x4>(dpp64_banks<0x12C, 0x1>(own, own), own);   // g=0 <- g+1, g=2 <- g-1
-        vals[2] = dpp64_banks<0x12C, 0x2>(dpp64_banks<0x128, 0x1>(own, own), own);   // g=0 <- g+2, g=1 <- g+1
     } else {
-        static_assert(D == 4, "gather_blocks: n_block in {1, 2, 3, 4} (more blocks go through LDS)");
-        // block k's value goes to tile g by a rotation of (g - k) tiles: one masked move per distance
-        vals[0] = dpp64_banks<0x12C, 0x8>(dpp64_banks<0x128, 0x4>(dpp64_banks<0x124, 0x2>(own, own), own), own);
-        vals[1] = dpp64_banks<0x128, 0x8>(dpp64_banks<0x124, 0x4>(dpp64_banks<0x12C, 0x1>(own, own), own), own);
-        vals[2] = dpp64_banks<0x124, 0x8>(dpp64_banks<0x12C, 0x2>(dpp64_banks<0x128, 0x1>(own, own), own), own);
-        vals[3] = dpp64_banks<0x12C, 0x4>(dpp64_banks<0x128, 0x2>(dpp64_banks<0x124, 0x1>(own, own), own), own);
+        static_assert(D == 3 || D == 4, "gather_blocks: n_block in {1, 2, 3, 4} (more blocks go through LDS)");
+        // three or four blocks: the wave carries ONE trajectory (tile g = block g) and a tile's value is the same in its 16
+        // lanes, so block k's value is lane 4 k of the wave, read into scalar registers: two v_readlane per value instead
+        // of two or three masked DPP rotations with a copy each (the generic p = 3 step of a three-variable ODE spent more
+        // time here than in its seven MFMAs)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(own), 4 * k), hi = __builtin_amdgcn_readlane(__double2hiint(own), 4 * k);
+            vals[k] = __hiloint2double(hi, lo);
+        }
     }
 }
 

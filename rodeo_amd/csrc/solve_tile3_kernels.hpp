@@ -220,6 +220,14 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
         store_row(M);
         return;
     }
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0, l4 = 0.0, XwL = 0.0;
+    if constexpr (rhs_has_tile3_form<RHS>::value && D == 3 && NW == 1) {
+        double kk[5];
+        RHS::tile3_consts(blk, th, kk);
+        const bool jac = ITG == RK_INTERROGATE_KRAMER;
+        l0 = jac ? 0.0 : -kk[0]; l1 = -kk[1]; l2 = -kk[2]; l3 = -kk[3]; l4 = -kk[4];          // a = -f + J0 own
+        XwL = fma(jac ? -kk[0] : 0.0, E0, Wr);                                                  // W~ = W - J: constant rows
+    }
     for (int n = 0; n < a.N; ++n) {
         // ---- predict (standard.py:57-59): U = (Q~ M)^T, M- = Q~ M Q~^T + R~; B0 = row 0 of Q~ M in every row ----
         // (a 4x4x4 fp64 MFMA blocks this wave's issue for ~17 cycles = 4 fp64 VALU ops, and nothing overlaps it --
@@ -251,6 +259,12 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
         if constexpr (rhs_has_tile_form<RHS>::value && D == 2) {
             const double v_oth = pair_other_quad_uniform(v_own);        // v_own is uniform in each quad
             Xw = fma(fma(fma(c3, v_own, c2), v_own, c1), v_own, fma(co, v_oth, c0));
+        } else if constexpr (rhs_has_tile3_form<RHS>::value && D == 3 && NW == 1) {
+            // Lorenz63-type right-hand sides (the form of fwd_tile4_kernel's trimmed step): the Jacobian entry is a constant,
+            // the offset a bilinear form of this block's and its neighbours' evaluation points (three plain DPP row rotations)
+            const double n1 = from_next_tile(v_own), p1 = from_prev_tile(v_own), p2 = dpp64<0x128>(v_own);
+            const double a_meas = fma(l4, p2 * p1, fma(l3, p1 * n1, fma(l2, p1, fma(l1, n1, l0 * v_own))));
+            Xw = fma(a_meas, e3r, XwL);
         } else {
             double X[D][P];
 #pragma unroll
