@@ -167,6 +167,8 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
 
     double tk[tile_form_consts<RHS>::N];
     if constexpr (rhs_has_tile_form<RHS>::value && D == 2) RHS::tile_consts(blk, th, tk);
+    double kk3[5];
+    if constexpr (rhs_has_tile3_form<RHS>::value && D == 3) RHS::tile3_consts(blk, th, kk3);
     for (int n = 0; n < a.N; ++n) {
         if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
             if ((n & 15) == 0) {                          // the 16 lanes of a unit draw z_0 for 16 consecutive steps
@@ -200,6 +202,12 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
             // two-block tile form (FitzHugh-Nagumo): the other block's point by one DPP move, per-lane coefficients
             RHS::tile_eval(tk, v_own, pair_other_quad_uniform(v_own), t, fb, J0);
             if constexpr (ITG != RK_INTERROGATE_KRAMER) J0 = 0.0;
+        } else if constexpr (rhs_has_tile3_form<RHS>::value && D == 3 && NW == 1) {
+            // Lorenz63-type right-hand sides: f is a bilinear form of this block's and its neighbours' evaluation points
+            // (three plain DPP row rotations), the Jacobian entry a constant (fwd_tile4_kernel's trimmed step)
+            const double n1 = from_next_tile(v_own), p1 = from_prev_tile(v_own), p2 = dpp64<0x128>(v_own);
+            fb = fma(kk3[4], p2 * p1, fma(kk3[3], p1 * n1, fma(kk3[2], p1, fma(kk3[1], n1, kk3[0] * v_own))));
+            J0 = ITG == RK_INTERROGATE_KRAMER ? kk3[0] : 0.0;
         } else {
         double X[D][1];
         if constexpr (NW == 1) {
