@@ -71,7 +71,10 @@ namespace rk {
 __global__ void placement_primer_kernel() {}
 
 void launch_placement_primer(rk_handle h, dim3 grid, dim3 block) {
-    if (grid.x >= 256) hipLaunchKernelGGL(placement_primer_kernel, grid, block, 0, h->stream);
+    // (only when the launch has more waves than half the chip's SIMDs: with fewer -- the benchmark's 512 -- no SIMD gets
+    // two either way, measured at B = 1024, and the empty launch would only cost its 5 us)
+    const unsigned waves = grid.x * ((block.x + 63) / 64);
+    if (waves > 2u * (unsigned)h->prop.multiProcessorCount) hipLaunchKernelGGL(placement_primer_kernel, grid, block, 0, h->stream);
 }
 }  // namespace rk
 

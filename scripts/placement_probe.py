@@ -24,7 +24,9 @@ for B in [int(v) for v in sys.argv[1:]] or [2048]:
         key = (xcc << 20) | (((ids >> 13) & 7) << 16) | (((ids >> 12) & 1) << 12) | (((ids >> 8) & 0xf) << 4) | ((ids >> 4) & 3)
         cnt = collections.Counter(key.tolist())
         hist = collections.Counter(cnt.values())
-        return {"distinct_simds": len(cnt), "simds_by_waves": dict(sorted(hist.items()))}
+        per_cu = collections.Counter((key >> 4).tolist())                   # waves per (xcc, se, sh, cu)
+        return {"distinct_simds": len(cnt), "simds_by_waves": dict(sorted(hist.items())),
+                "cus_by_waves": dict(sorted(collections.Counter(per_cu.values()).items()))}
 
     def timed(seq_before):
         out = []
