@@ -56,6 +56,7 @@ struct DenseArgs {
     unsigned long long seed, traj_offset;      // Philox stream of the draws (interrogate_chkrebtii, solve_sim)
     double* x;                                 // solve_sim: draws, batch-minor like the lane kernels: x[(n p + i) B + b]
     double *mean_pred, *var_pred;              // RK_FLAG_STORE_PRED (_solve_filter): (B, N+1, p), (B, N+1, p, p), or null
+    double* fac_pred;                          // square-root form: the predicted factors L^-_n (B, N+1, p, p) for the backward pass, or null
 };
 
 constexpr int DT = 512, NWAVE = DT / 64;
@@ -864,7 +865,7 @@ __device__ __forceinline__ DenseWs carve(double* w, int p, int m) {
     return d;
 }
 
-size_t dense_ws_doubles(int p, int m) {
+static size_t dense_ws_doubles(int p, int m) {
     return 4 * (size_t)p * p + 3 * (size_t)m * p + (size_t)m * m + 2 * (size_t)p + 2 * (size_t)m + (size_t)(p + 1) / 2 + 16;
 }
 
@@ -1302,6 +1303,12 @@ __global__ void __launch_bounds__(DT) dense_bwd_sim_kernel(DenseArgs a) {
     (void)m;
 }
 
+}  // namespace rk
+
+#include "solve_dense_sqrt.hpp"
+
+namespace rk {
+
 bool is_user_rhs(int rhs_id);
 bool user_dense_wanted(const rk_solve_cfg* c);
 int user_dense_interrogate(rk_handle h, const rk_solve_cfg* c, const DenseItgArgs& a);
@@ -1318,7 +1325,13 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
                "dense linear ODE: n_bstate (%d) must be n_vars * n_deriv with n_vars = n_bmeas (%d), n_deriv >= 2",
                c->n_bstate, c->n_bmeas);
     RK_REQUIRE(c->n_bstate <= 768, RK_ERR_UNSUPPORTED, "dense path: n_bstate = %d exceeds 768 (LDS staging of the GEMMs)", c->n_bstate);
-    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "dense path: kalman_type must be standard");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD || c->kalman_type == RK_KALMAN_SQRT, RK_ERR_UNSUPPORTED,
+               "dense path: unknown kalman_type %d", c->kalman_type);
+    // interrogate.py:36-42: in square-root mode the reference draws mu- + (W L-) z, an (n_bmeas,) vector added to an
+    // (n_bstate,) one -- it only broadcasts for n_bmeas = 1 or n_bstate, neither of which is a dense-path shape
+    RK_REQUIRE(!(c->kalman_type == RK_KALMAN_SQRT && c->interrogate == RK_INTERROGATE_CHKREBTII), RK_ERR_UNSUPPORTED,
+               "dense path: interrogate_chkrebtii with kalman_type=square-root is undefined for 1 < n_bmeas < n_bstate "
+               "(the reference's draw mu- + (W L-) z does not broadcast, src/rodeo/interrogate.py:36-42)");
     RK_REQUIRE(!(c->flags & RK_FLAG_BATCH_MINOR), RK_ERR_UNSUPPORTED, "dense path: its layout is trajectory-major (RK_FLAG_BATCH_MINOR)");
     RK_REQUIRE(!in->ode_weight_batched && !in->prior_weight_batched && !in->prior_var_batched, RK_ERR_UNSUPPORTED,
                "dense path: ode_weight and prior_pars must be shared by all trajectories");
@@ -1330,11 +1343,26 @@ int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode) {
     return RK_OK;
 }
 
+// Bytes of out->workspace a dense solve needs.  Square-root form: per-trajectory scratch, then -- for the backward passes,
+// unless the caller keeps the predictions anyway (RK_FLAG_STORE_PRED) -- the predicted factors of every step
+// (B, N+1, p, p): square_root.py:170-175 solves with L^-_{n+1}, and recomputing it would repeat the forward pass's
+// most expensive operation (a 2p x p QR) where storing it costs p^2 doubles per step of 288 GB.
+static bool dense_sqrt_keeps_pred_in_ws(const rk_solve_cfg* c, int mode) {
+    return c->kalman_type == RK_KALMAN_SQRT && mode != RK_MODE_FILTER && !(c->flags & RK_FLAG_STORE_PRED);
+}
+size_t dense_ws_bytes(const rk_solve_cfg* c, int mode) {
+    const size_t p = c->n_bstate, B = c->n_traj;
+    if (c->kalman_type == RK_KALMAN_SQRT)
+        return (dense_sq_ws_doubles(c->n_bstate, c->n_bmeas) * B +
+                (dense_sqrt_keeps_pred_in_ws(c, mode) ? B * (size_t)(c->n_steps + 1) * p * p : 0)) * sizeof(double);
+    return dense_ws_doubles(c->n_bstate, c->n_bmeas) * B * sizeof(double);
+}
+
 int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, int mode) {
     RK_REQUIRE(out->workspace, RK_ERR_INVALID, "dense path needs out->workspace (rk_solve_workspace_bytes)");
     {
         // every kernel below indexes the workspace by trajectory with this stride: check the caller's size on the host
-        const size_t need = dense_ws_doubles(c->n_bstate, c->n_bmeas) * (size_t)c->n_traj * sizeof(double);
+        const size_t need = dense_ws_bytes(c, mode);
         RK_REQUIRE(out->workspace_bytes >= need, RK_ERR_INVALID,
                    "dense path: out->workspace_bytes = %zu, this configuration needs %zu (rk_solve_workspace_bytes)",
                    out->workspace_bytes, need);
@@ -1354,6 +1382,47 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
     RK_REQUIRE(!(c->flags & RK_FLAG_STORE_PRED) || (out->mean_pred && out->var_pred), RK_ERR_INVALID,
                "RK_FLAG_STORE_PRED needs out->mean_pred / var_pred");
     RK_REQUIRE(mode != RK_MODE_SIM || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");
+    a.fac_pred = nullptr;
+    if (c->kalman_type == RK_KALMAN_SQRT) {
+        // ---- square-root form (solve_dense_sqrt.hpp) ----
+        a.ws_stride = dense_sq_ws_doubles(a.p, a.m);
+        if (c->flags & RK_FLAG_STORE_PRED) a.fac_pred = out->var_pred;
+        else if (dense_sqrt_keeps_pred_in_ws(c, mode)) a.fac_pred = a.ws + a.ws_stride * (size_t)a.B;
+        if (c->rhs_id == RK_RHS_LINEAR_DENSE) {
+            LaunchTimer t(h, "dense_sqrt_fwd_kernel");
+            hipLaunchKernelGGL((dense_sqrt_fwd_kernel<0>), dim3(a.B), dim3(DT), 0, h->stream, a);
+            t.stop();
+        } else {
+            DenseItgArgs g;
+            g.B = a.B; g.N = a.N; g.t_min = a.t_min; g.t_max = a.t_max; g.W = a.W; g.theta = a.theta; g.theta_b = a.theta_b;
+            g.ws = a.ws; g.ws_stride = a.ws_stride;
+            g.off_Wt = dense_sq_off_Wt(a.p); g.off_mup = dense_sq_off_mup(a.p, a.m); g.off_am = g.off_mup + a.p; g.off_x = g.off_mup;
+            LaunchTimer t(h, "dense_sqrt_fwd_kernel<user, stepwise>");
+            hipLaunchKernelGGL((dense_sqrt_fwd_kernel<1>), dim3(a.B), dim3(DT), 0, h->stream, a);
+            for (int n = 0; n < a.N; ++n) {
+                g.n = n;
+                const int rc = user_dense_interrogate(h, c, g);
+                if (rc) { t.stop(); return rc; }
+                a.n0 = n;
+                hipLaunchKernelGGL((dense_sqrt_fwd_kernel<2>), dim3(a.B), dim3(DT), 0, h->stream, a);
+            }
+            t.stop();
+        }
+        RK_HIP(hipGetLastError());
+        if (mode == RK_MODE_SIM) {
+            LaunchTimer t(h, "dense_sqrt_bwd_sim_kernel");
+            hipLaunchKernelGGL(dense_sqrt_bwd_sim_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+            t.stop();
+            RK_HIP(hipGetLastError());
+        }
+        if (mode == RK_MODE_MV && a.N >= 2) {
+            LaunchTimer t(h, "dense_sqrt_bwd_mv_kernel");
+            hipLaunchKernelGGL(dense_sqrt_bwd_mv_kernel, dim3(a.B), dim3(DT), 0, h->stream, a);
+            t.stop();
+            RK_HIP(hipGetLastError());
+        }
+        return RK_OK;
+    }
     hipLaunchKernelGGL(dense_qcheck_kernel, dim3(1), dim3(256), 0, h->stream, a.Q, a.p, a.p / a.m, a.ws + a.ws_stride - 1);
     const bool extra = c->interrogate == RK_INTERROGATE_CHKREBTII || (c->flags & RK_FLAG_STORE_PRED);
     if (c->rhs_id == RK_RHS_LINEAR_DENSE) {

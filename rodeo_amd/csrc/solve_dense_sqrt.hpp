@@ -1,0 +1,716 @@
+// Dense square-root filter / smoother / sampler: kalman_type = "square-root" on the non-block path (one dense block of
+// n_vars * n_deriv states, prior.indep_init), i.e. src/rodeo/kalmantv/square_root.py:30-261 with src/rodeo/utils.py:10-24
+// (add_sqrt = R^T of the QR of the stacked transposed factors) inside the time loops of src/rodeo/solve.py:31-122,
+// 137-205, 257-301.  Included by solve_dense.hip (same translation unit: it shares the workgroup's LDS, wg_gemm,
+// lu_rank_update and the substitution kernels of the covariance-form path).
+//
+// Why it exists: in covariance form the reference's recursion is numerically dead on BASELINE config 5 (stiff linear
+// ODE, exact measurement: |x - expm(A) x0| = 6e8 at t = 1 on the oracle and on the device alike); the square-root form
+// of the same reference reaches 1.8e-8.
+//
+// Representation: every factor is kept as the reference keeps it -- LOWER triangular L, row-major, in the var arrays
+// (solve.py returns the factors in this mode).  A QR only ever produces R (never Q): add_sqrt(A, B) = R^T.
+//
+// Building blocks (all workgroup-wide, 512 threads, operands in global memory / L2):
+//   wg_qr_r        blocked Householder QR of a stacked M x n matrix, R only: 16-column panels in compact WY form
+//                  (H_1 ... H_16 = I - V T V^T).  Per panel: (i) the panel is factored with the columns spread over
+//                  lanes -- lane (slab, c) of the 32 slabs of 16 lanes holds column c of the panel's 16 triangle rows
+//                  (replicated in every slab) and of its slab's share of the rows below, so a dot product of the pivot
+//                  column with all 16 columns is ONE value per lane, reduced over the slabs by two shuffles and one LDS
+//                  exchange (one barrier per column); LAPACK dlarfg's beta / tau / scaling; (ii) V^T V on
+//                  v_mfma_f64_16x16x4 (both fragments are the same LDS read), T by 16 lanes (dlarft's forward
+//                  recurrence) while the other waves already run (iii) W = V^T A2 on MFMA with V from the LDS panel and
+//                  A2 streamed from memory; (iv) W <- T^T W in LDS; (v) A2 <- A2 - V W = the LU path's rank-16 update.
+//   wg_tri_solve   X = E^{-1} B for a triangular E given as a row-major triangle or its transpose, both directions,
+//                  the right-hand side resident in registers (the back substitution of the LU path, generalised).
+//   wg_transpose   dst = src^T through LDS bands (optionally only the upper triangle of src: L = R^T).
+#pragma once
+
+namespace rk {
+
+constexpr int QR_RT = 15;                               // panel rows below the triangle per lane: panels of up to 496 rows
+constexpr int QR_MAXM = 16 + 32 * QR_RT;
+
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double bperm_f64(double x, int byte_addr) {
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(x)),
+                            __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(x)));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dst (rows x cols, ldd) = src^T, src (cols x rows, lds_).  tri != 0: src is upper triangular (square), only src[j][i]
+// with j <= i is read and dst gets exact zeros above its diagonal (L = R^T).  Bands of 16 dst rows through LDS
+// (buf[j][ti], row stride 17): the loads read 128-byte pieces of src rows, the stores write whole dst rows.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __noinline__ void wg_transpose(double* dst_, int ldd_, const double* src_, int lds__, int rows_, int cols_, int tri_) {
+    auto* const dst = uni_g(dst_);
+    auto* const src = uni_g(src_);
+    const int ldd = uni(ldd_), lds_ = uni(lds__), rows = uni(rows_), cols = uni(cols_), tri = uni(tri_);
+    double* const buf = g_lds;
+    const int cmax = LDS_DOUBLES / 17;                  // columns per pass
+    for (int j0 = 0; j0 < cols; j0 += cmax) {
+        const int jn = min(cmax, cols - j0);
+        for (int i0 = 0; i0 < rows; i0 += 16) {
+            const int in = min(16, rows - i0);
+            const int jhi = tri ? min(jn, i0 + 16 - j0) : jn;          // src rows that can be non-zero in this band
+            __syncthreads();
+            for (int e = threadIdx.x; e < jhi * 16; e += DT) {
+                const int j = e >> 4, ti = e & 15;
+                buf[j * 17 + ti] = ti < in ? src[(size_t)(j0 + j) * lds_ + i0 + ti] : 0.0;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < in * jn; e += DT) {
+                const int ti = e / jn, j = e - ti * jn;
+                const bool nz = !tri || (j0 + j <= i0 + ti);
+                dst[(size_t)(i0 + ti) * ldd + j0 + j] = (nz && j < jhi) ? buf[j * 17 + ti] : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Panel factorisation (see the file header).  Thread t: column c = t & 15 of slab s = t >> 4; tri[i] = panel row i
+// (i < 16, replicated over the slabs), tall[i] = panel row 16 + s + 32 i.
+// ---------------------------------------------------------------------------------------------------------------
+template <int J>
+__device__ __forceinline__ void qr_panel_col(double (&tr)[16], double (&ta)[QR_RT], int c, int src_addr, int wave, int lane,
+                                             int pg_off, int tau_off) {
+    // the pivot column: triangle rows from lane J (every slab holds them), the slab's tall rows from lane (slab, J)
+    double pt[16], pu[QR_RT];
+#pragma unroll
+    for (int i = J; i < 16; ++i) pt[i] = readlane_f64(tr[i], J);
+#pragma unroll
+    for (int i = 0; i < QR_RT; ++i) pu[i] = bperm_f64(ta[i], src_addr);
+    double gt = 0.0, nt = 0.0, gu = 0.0, nu = 0.0;
+#pragma unroll
+    for (int i = J + 1; i < 16; ++i) { gt = fma(pt[i], tr[i], gt); nt = fma(pt[i], pt[i], nt); }
+#pragma unroll
+    for (int i = 0; i < QR_RT; ++i) { gu = fma(pu[i], ta[i], gu); nu = fma(pu[i], pu[i], nu); }
+    gu += __shfl_xor(gu, 16); nu += __shfl_xor(nu, 16);
+    gu += __shfl_xor(gu, 32); nu += __shfl_xor(nu, 32);
+    double* const bb = g_lds + pg_off + (J & 1) * 136;  // [c][wave] partial dots, then [wave] partial norms
+    if (lane < 16) bb[c * 8 + wave] = gu;
+    if (lane == 0) bb[128 + wave] = nu;
+    __syncthreads();
+    double G = 0.0, Nn = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) { G += bb[c * 8 + w]; Nn += bb[128 + w]; }
+    // LAPACK dlarfg: beta = -sign(alpha) ||(alpha, x)||, tau = (beta - alpha) / beta, v = x / (alpha - beta), v_J = 1
+    const double alpha = pt[J], xn2 = nt + Nn;
+    const bool refl = xn2 != 0.0;
+    const double beta = refl ? -copysign(sqrt(fma(alpha, alpha, xn2)), alpha) : alpha;
+    const double tau = refl ? (beta - alpha) / beta : 0.0;
+    const double scale = refl ? 1.0 / (alpha - beta) : 0.0;
+    if (threadIdx.x == 0) g_lds[tau_off + J] = tau;
+    // w_c = tau (a_Jc + v_below . a_c) for the columns right of J; column J itself becomes (beta, v)
+    const bool right = c > J, piv = c == J;
+    const double wc = right ? tau * fma(scale, gt + G, tr[J]) : 0.0;
+    tr[J] = piv ? beta : tr[J] - wc;
+#pragma unroll
+    for (int i = J + 1; i < 16; ++i) { const double v = pt[i] * scale; tr[i] = piv ? v : fma(-v, wc, tr[i]); }
+#pragma unroll
+    for (int i = 0; i < QR_RT; ++i) { const double v = pu[i] * scale; ta[i] = piv ? v : fma(-v, wc, ta[i]); }
+}
+template <int J>
+__device__ __forceinline__ void qr_panel_cols(double (&tr)[16], double (&ta)[QR_RT], int c, int src_base, int wave, int lane,
+                                              int nb, int pg_off, int tau_off) {
+    if constexpr (J < 16) {
+        if (J < nb) qr_panel_col<J>(tr, ta, c, src_base + 4 * J, wave, lane, pg_off, tau_off);
+        else if (threadIdx.x == 0) g_lds[tau_off + J] = 0.0;
+        qr_panel_cols<J + 1>(tr, ta, c, src_base, wave, lane, nb, pg_off, tau_off);
+    }
+}
+
+// Factors the panel P (Mk rows, nb <= 16 columns, row stride ld, in global memory): R11's upper triangle back to P, V (unit
+// lower trapezoid, explicit ones and zeros) to the LDS panel g_lds[r * LU_LD + c], tau to g_lds[tau_off ..].
+__device__ __noinline__ void qr_panel(double* P_, int ld_, int Mk_, int nb_, int pg_off_, int tau_off_) {
+    auto* const P = uni_g(P_);
+    const int ld = uni(ld_), Mk = uni(Mk_), nb = uni(nb_), pg_off = uni(pg_off_), tau_off = uni(tau_off_);
+    const int tid = threadIdx.x, c = tid & 15, s = tid >> 4, lane = tid & 63, wave = uni((int)(tid >> 6));
+    double tr[16], ta[QR_RT];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tr[i] = (c < nb && i < Mk) ? P[(size_t)i * ld + c] : 0.0;
+#pragma unroll
+    for (int i = 0; i < QR_RT; ++i) {
+        const int r = 16 + s + 32 * i;
+        ta[i] = (c < nb && r < Mk) ? P[(size_t)r * ld + c] : 0.0;
+    }
+    qr_panel_cols<0>(tr, ta, c, 4 * (lane & 48), wave, lane, nb, pg_off, tau_off);
+    double* const panel = g_lds;
+    if (s == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < Mk) panel[i * LU_LD + c] = i > c ? tr[i] : ((i == c && c < nb) ? 1.0 : 0.0);
+            if (i <= c && c < nb && i < Mk) P[(size_t)i * ld + c] = tr[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QR_RT; ++i) {
+        const int r = 16 + s + 32 * i;
+        if (r < Mk) panel[r * LU_LD + c] = ta[i];
+    }
+    __syncthreads();
+}
+
+// T (16 x 16 upper triangular, g_lds[t_off + i * 16 + j]) of the compact WY form from the LDS panel V and tau:
+// T_jj = tau_j, T(0:j, j) = -tau_j T(0:j, 0:j) (V^T V)(0:j, j)   (LAPACK dlarft, forward / columnwise).
+// Ends WITHOUT a barrier: T is complete after the caller's next barrier.
+__device__ __noinline__ void qr_build_T(int Mk_, int gp_off_, int t_off_, int tau_off_) {
+    const int Mk = uni(Mk_), gp_off = uni(gp_off_), t_off = uni(t_off_), tau_off = uni(tau_off_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(tid >> 6)), lo = lane & 15, hi = lane >> 4;
+    const double* const panel = g_lds;
+    double* const gp = g_lds + gp_off;
+    d4 acc = d4{0, 0, 0, 0};
+    for (int r0 = 4 * wave; r0 < Mk; r0 += 4 * NWAVE) {
+        const int r = r0 + hi;
+        const double a = r < Mk ? panel[r * LU_LD + lo] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) gp[wave * 256 + (4 * v + hi) * 16 + lo] = acc[v];
+    __syncthreads();
+    if (tid < 256) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) sacc += gp[w * 256 + tid];
+        gp[tid] = sacc;                                  // (its own element of slot 0: nobody else reads or writes it)
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int i = tid;
+        double Tr[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double tau_j = g_lds[tau_off + j];
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < j; ++k) sacc = fma(k >= i ? Tr[k] : 0.0, gp[k * 16 + j], sacc);
+            Tr[j] = i == j ? tau_j : (i < j ? -tau_j * sacc : 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g_lds[t_off + i * 16 + j] = Tr[j];
+    }
+}
+
+// W (16 x n2, LDS strip us[k * usp + j]) = V^T A2, A2 = the Mk x n2 matrix right of the panel (global, row stride lda):
+// wave w owns the column tiles w, w + 8, ...; per 4 rows one MFMA with the A fragment from the LDS panel and the B
+// fragment straight from memory (the next group's loads are issued before the current group's MFMAs).
+__device__ __noinline__ void qr_w_pass(const double* A2_, int lda_, int Mk_, int n2_, int us_off_, int usp_) {
+    auto* const A2 = uni_g(A2_);
+    const int lda = uni(lda_), Mk = uni(Mk_), n2 = uni(n2_), usp = uni(usp_);
+    const double* const panel = g_lds;
+    double* const us = g_lds + uni(us_off_);
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
+    const int nct = (n2 + 15) >> 4;
+    constexpr int UB = 8;
+    for (int ct = wave; ct < nct; ct += NWAVE) {
+        const int j = ct * 16 + lo;
+        const bool cok = j < n2;
+        auto load = [&](int r0, double (&b)[UB]) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int r = r0 + 4 * u + hi;
+                b[u] = (cok && r < Mk) ? A2[(size_t)r * lda + j] : 0.0;
+            }
+        };
+        d4 acc = d4{0, 0, 0, 0};
+        double cur[UB], nxt[UB];
+        load(0, cur);
+        for (int r0 = 0; r0 < Mk; r0 += 4 * UB) {
+            load(r0 + 4 * UB, nxt);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int r = r0 + 4 * u + hi;
+                const double a = r < Mk ? panel[r * LU_LD + lo] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, cur[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) cur[u] = nxt[u];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) us[(4 * v + hi) * usp + ct * 16 + lo] = acc[v];
+    }
+}
+
+// W <- T^T W in the LDS strip, one thread per column
+__device__ __forceinline__ void qr_apply_T(int ncols, double* us, int usp, const double* T) {
+    for (int c = threadIdx.x; c < ncols; c += DT) {
+        double w[16], o[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = us[k * usp + c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k <= i; ++k) sacc = fma(T[k * 16 + i], w[k], sacc);
+            o[i] = sacc;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) us[i * usp + c] = o[i];
+    }
+}
+
+// Fallback beyond the LDS panel's limits: column-by-column Householder in global memory (one wave per trailing column).
+__device__ __noinline__ void wg_qr_r_unblocked(double* S_, int ld_, int M_, int n_) {
+    auto* const S = uni_g(S_);
+    const int ld = uni(ld_), M = uni(M_), n = uni(n_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(tid >> 6));
+    double* const red = g_lds;
+    for (int j = 0; j < n && j < M; ++j) {
+        double part = 0.0;
+        for (int r = j + 1 + tid; r < M; r += DT) { const double x = S[(size_t)r * ld + j]; part = fma(x, x, part); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        double xn2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) xn2 += red[w];
+        const double alpha = S[(size_t)j * ld + j];
+        const bool refl = xn2 != 0.0;
+        const double beta = refl ? -copysign(sqrt(fma(alpha, alpha, xn2)), alpha) : alpha;
+        const double tau = refl ? (beta - alpha) / beta : 0.0;
+        const double scale = refl ? 1.0 / (alpha - beta) : 0.0;
+        for (int c = j + 1 + wave; c < n; c += NWAVE) {
+            double dot = 0.0;
+            for (int r = j + 1 + lane; r < M; r += 64) dot = fma(S[(size_t)r * ld + j], S[(size_t)r * ld + c], dot);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+            const double wc = tau * fma(scale, dot, S[(size_t)j * ld + c]);
+            for (int r = j + 1 + lane; r < M; r += 64) S[(size_t)r * ld + c] = fma(-(S[(size_t)r * ld + j] * scale), wc, S[(size_t)r * ld + c]);
+            if (lane == 0) S[(size_t)j * ld + c] -= wc;
+        }
+        __syncthreads();
+        if (tid == 0) S[(size_t)j * ld + j] = beta;
+        __syncthreads();
+    }
+}
+
+// In place: the upper triangle of the top n x n block of S (M x n, row stride ld, M >= 1) becomes the R of S's QR
+// factorisation (LAPACK's sign convention: r_jj = -sign(a_jj) ||.||); everything below the diagonal is left undefined.
+__device__ __noinline__ void wg_qr_r(double* S_, int ld_, int M_, int n_) {
+    auto* const S = uni_g(S_);
+    const int ld = uni(ld_), M = uni(M_), n = uni(n_);
+    const int npad = (n + 15) & ~15;
+    const int us_off = M * LU_LD, usp = (npad + 16) | 1;
+    const int gp_off = us_off + 16 * usp, t_off = gp_off + NWAVE * 256, tau_off = t_off + 256, pg_off = tau_off + 16;
+    if (M > QR_MAXM || pg_off + 2 * 136 > LDS_DOUBLES) { wg_qr_r_unblocked((double*)S, ld, M, n); return; }
+    __syncthreads();
+    for (int k0 = 0; k0 < n && k0 < M; k0 += 16) {
+        const int nb = min(16, n - k0), Mk = M - k0, n2 = n - k0 - nb;
+        qr_panel((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
+        if (n2 > 0) {
+            qr_build_T(Mk, gp_off, t_off, tau_off);
+            qr_w_pass((const double*)(S + (size_t)k0 * ld + k0 + nb), ld, Mk, n2, us_off, usp);
+            __syncthreads();
+            qr_apply_T((n2 + 15) & ~15, g_lds + us_off, usp, g_lds + t_off);
+            __syncthreads();
+            lu_rank_update(0, Mk, 16, us_off, usp, (Mk + 15) >> 4, (double*)(S + (size_t)k0 * ld + k0 + nb), ld, n2, (n2 + 15) >> 4,
+                           (double*)(S + (size_t)k0 * ld + k0 + nb), ld, 0, 0, 0, Mk);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// X = E^{-1} B in place, E triangular (n x n, non-unit diagonal), E[i][j] = trans ? T[j][i] : T[i][j]; LOWER: E is lower
+// triangular (forward substitution from the top), else upper (back substitution from the bottom).  n, nr <= 160: the
+// right-hand side stays in registers (lu_backsub_regs' scheme: 100 tiles over 8 waves; per 16-row block the block
+// column of E is staged in LDS, the owners of the block's tiles pass them through LDS scratches to 16 threads per
+// column tile for the 16 x 16 substitution, and every wave updates its remaining tiles with rank-16 MFMAs).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool LOWER>
+__device__ __noinline__ void tri_trsm_all(int k0_, int nb_, int nct_) {
+    const int k0 = uni(k0_), nb = uni(nb_), nct = uni(nct_);
+    if ((int)threadIdx.x >= 16 * nct) return;
+    const double* const panel = g_lds;
+    double* const scratch = g_lds + BS_SCR + (threadIdx.x >> 4) * 16 * LU_LD;
+    const int lo = threadIdx.x & 15;
+    double x[LU_NB];
+#pragma unroll
+    for (int j = 0; j < LU_NB; ++j) x[j] = j < nb ? scratch[j * LU_LD + lo] : 0.0;
+    if (LOWER) {
+#pragma unroll
+        for (int j = 0; j < LU_NB; ++j) {
+            int pj = (k0 + j) * LU_LD;
+            if (j > 0) asm("" : "+v"(pj) : "v"(x[j - 1]));                // (see lu_trsm_lower: keeps the reads from piling up)
+            double sacc = x[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) sacc = fma(-panel[pj + i], x[i], sacc);
+            x[j] = j < nb ? sacc * g_rdiag[j] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int j = LU_NB - 1; j >= 0; --j) {
+            int pj = (k0 + j) * LU_LD;
+            if (j < LU_NB - 1) asm("" : "+v"(pj) : "v"(x[j + 1]));
+            double sacc = x[j];
+#pragma unroll
+            for (int i = j + 1; i < LU_NB; ++i)
+                if (i < nb) sacc = fma(-panel[pj + i], x[i], sacc);
+            x[j] = j < nb ? sacc * g_rdiag[j] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LU_NB; ++j) scratch[j * LU_LD + lo] = x[j];
+}
+
+template <bool LOWER>
+__device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int trans_, double* Bm_, int ldb_, int n_, int nr_) {
+    auto* const T = uni_g(T_);
+    auto* const Bm = uni_g(Bm_);
+    const int ldt = uni(ldt_), trans = uni(trans_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
+    const int nbk = (n + 15) >> 4, nct = (nr + 15) >> 4;
+    double* const panel = g_lds;
+    double* const scr = g_lds + BS_SCR;
+    d4 t[BS_Q];
+#pragma unroll
+    for (int q = 0; q < BS_Q; ++q) {
+        const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * rb + 4 * v + hi, col = 16 * ct + lo;
+            double y = Bm[min(row, n - 1) * ldb + min(col, nr - 1)];
+            asm("" : "+v"(y));
+            t[q][v] = (row < n && col < nr) ? y : 0.0;
+        }
+    }
+    for (int kk = 0; kk < nbk; ++kk) {
+        const int k = LOWER ? kk : nbk - 1 - kk;
+        const int k0 = 16 * k, nb = min(16, n - k0);
+        const int r_lo = LOWER ? k0 : 0, nrow = LOWER ? n - k0 : k0 + nb;
+        __syncthreads();                                            // the previous block's panel and scratches are free
+        if (!trans) {
+            for (int e = threadIdx.x; e < nrow * LU_NB; e += DT) {
+                const int r = r_lo + (e >> 4), c = e & 15;
+                panel[r * LU_LD + c] = c < nb ? T[r * ldt + k0 + c] : 0.0;
+            }
+        } else {
+            for (int e = threadIdx.x; e < nrow * LU_NB; e += DT) {
+                const int c = e / nrow, r = r_lo + (e - c * nrow);
+                panel[r * LU_LD + c] = c < nb ? T[(k0 + c) * ldt + r] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BS_Q; ++q) {
+            const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+            if (rb == k && ct < nct) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) scr[ct * 16 * LU_LD + (4 * v + hi) * LU_LD + lo] = t[q][v];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < nb) g_rdiag[threadIdx.x] = 1.0 / panel[(k0 + threadIdx.x) * LU_LD + threadIdx.x];
+        __syncthreads();
+        tri_trsm_all<LOWER>(k0, nb, nct);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BS_Q; ++q) {
+            const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+            if (ct < nct && rb < nbk) {
+                const double* const sc = scr + ct * 16 * LU_LD;
+                if (rb == k) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) t[q][v] = sc[(4 * v + hi) * LU_LD + lo];
+                } else if (LOWER ? rb > k : rb < k) {               // Y_rb -= E(rb, k) X_k
+                    const int er = min(16 * rb + lo, n - 1);
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+                        t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-panel[er * LU_LD + 4 * kq + hi],
+                                                                    sc[(4 * kq + hi) * LU_LD + lo], t[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BS_Q; ++q) {
+        const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 16 * rb + 4 * v + hi, col = 16 * ct + lo;
+            if (e < BS_T * BS_T && row < n && col < nr) Bm[row * ldb + col] = t[q][v];
+        }
+    }
+    __syncthreads();
+}
+
+// any size: one thread per right-hand-side column, everything in global memory (slow; beyond 160 x 160 only)
+template <bool LOWER>
+__device__ __noinline__ void wg_tri_solve_slow(const double* T_, int ldt_, int trans_, double* Bm_, int ldb_, int n_, int nr_) {
+    auto* const T = uni_g(T_);
+    auto* const Bm = uni_g(Bm_);
+    const int ldt = uni(ldt_), trans = uni(trans_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
+    for (int c = threadIdx.x; c < nr; c += DT) {
+        for (int kk = 0; kk < n; ++kk) {
+            const int k = LOWER ? kk : n - 1 - kk;
+            const double xk = Bm[(size_t)k * ldb + c] / (trans ? T[(size_t)k * ldt + k] : T[(size_t)k * ldt + k]);
+            Bm[(size_t)k * ldb + c] = xk;
+            if (LOWER) for (int i = k + 1; i < n; ++i)
+                Bm[(size_t)i * ldb + c] = fma(-(trans ? T[(size_t)k * ldt + i] : T[(size_t)i * ldt + k]), xk, Bm[(size_t)i * ldb + c]);
+            else for (int i = 0; i < k; ++i)
+                Bm[(size_t)i * ldb + c] = fma(-(trans ? T[(size_t)k * ldt + i] : T[(size_t)i * ldt + k]), xk, Bm[(size_t)i * ldb + c]);
+        }
+    }
+    __syncthreads();
+}
+
+template <bool LOWER>
+__device__ __forceinline__ void wg_tri_solve(const double* T, int ldt, int trans, double* Bm, int ldb, int n, int nr) {
+    if (n <= 16 * BS_T && nr <= 16 * BS_T) wg_tri_solve_regs<LOWER>(T, ldt, trans, Bm, ldb, n, nr);
+    else wg_tri_solve_slow<LOWER>(T, ldt, trans, Bm, ldb, n, nr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Workspace of one trajectory (doubles), shared by the three kernels below.
+// ---------------------------------------------------------------------------------------------------------------
+struct DenseSqWs {
+    double *S, *A1, *A2, *A3, *Wt, *WS, *X, *W2, *Sm, *Vh, *mup, *f, *yhat, *dm;
+};
+__host__ __device__ inline size_t dense_sq_off_Wt(int p) { return 6 * (size_t)p * p; }
+__host__ __device__ inline size_t dense_sq_off_mup(int p, int m) {
+    return 6 * (size_t)p * p + 4 * (size_t)m * p + ((size_t)p + m) * m + (size_t)m * m;
+}
+__device__ __forceinline__ DenseSqWs carve_sq(double* w, int p, int m) {
+    DenseSqWs d;
+    const size_t pp = (size_t)p * p, mp = (size_t)m * p;
+    d.S = w; d.A1 = d.S + 3 * pp; d.A2 = d.A1 + pp; d.A3 = d.A2 + pp;
+    d.Wt = d.A3 + pp; d.WS = d.Wt + mp; d.X = d.WS + mp; d.W2 = d.X + mp;
+    d.Sm = d.W2 + mp; d.Vh = d.Sm + ((size_t)p + m) * m;
+    d.mup = d.Vh + (size_t)m * m; d.f = d.mup + p; d.yhat = d.f + m; d.dm = d.yhat + m;
+    return d;
+}
+size_t dense_sq_ws_doubles(int p, int m) {
+    return dense_sq_off_mup(p, m) + 2 * (size_t)p + 2 * (size_t)m + 16;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward pass, square-root form (solve.py:31-122 with square_root.py:56-57 and 88-99).  MODE as in dense_fwd_kernel.
+// a.var: the filtered factors L_n (lower), a.fac_pred: the predicted factors L^-_n (or null: not kept).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
+    const int b = blockIdx.x, p = a.p, m = a.m;
+    const int nd = p / m;
+    const DenseSqWs w = carve_sq(a.ws + (size_t)b * a.ws_stride, p, m);
+    double* mean = a.mean + (size_t)b * (a.N + 1) * p;
+    double* var = a.var + (size_t)b * (a.N + 1) * p * p;
+    double* facp = a.fac_pred ? a.fac_pred + (size_t)b * (a.N + 1) * p * p : nullptr;
+    double* meanp = a.mean_pred ? a.mean_pred + (size_t)b * (a.N + 1) * p : nullptr;
+    const double* Aode = a.theta;
+    const bool noisy = a.itg == RK_INTERROGATE_RODEO;              // var_meas != 0 (interrogate.py:110-113)
+    const int kv = noisy ? m : 0;
+    if (MODE != 2) {
+        for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
+        for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
+        if (facp) for (int e = threadIdx.x; e < p * p; e += DT) facp[e] = 0.0;
+        if (meanp) for (int i = threadIdx.x; i < p; i += DT) meanp[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
+    }
+    __syncthreads();
+    auto predict = [&](int n) {
+        const double* mu = mean + (size_t)n * p;
+        const double* Ln = var + (size_t)n * p * p;
+        double* Lp = facp ? facp + (size_t)(n + 1) * p * p : w.A2;
+        // square_root.py:56-57: L^- = add_sqrt(Q L, R^{1/2}) = R^T of qr([ (Q L)^T ; R^{1/2 T} ])
+        wg_gemm(gemm_op(w.S, p, Ln, p, true, a.Q, p, true, p, p, p, nullptr, 0, 0.0, 1.0));
+        wg_transpose(w.S + (size_t)p * p, p, a.R, p, p, p, 0);
+        wg_qr_r(w.S, p, 2 * p, p);
+        wg_transpose(Lp, p, w.S, p, p, p, 1);
+        wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
+        if (meanp) {
+            for (int i = threadIdx.x; i < p; i += DT) meanp[(size_t)(n + 1) * p + i] = w.mup[i];
+            __syncthreads();
+        }
+    };
+    auto update = [&](int n) {
+        const double* Lp = facp ? facp + (size_t)(n + 1) * p * p : w.A2;
+        double* mu_o = mean + (size_t)(n + 1) * p;
+        double* L_o = var + (size_t)(n + 1) * p * p;
+        // ---- interrogation (as in dense_fwd_kernel): W~ in w.Wt, yhat = W~ mu- + a ----
+        if (MODE == 0) {
+            for (int e = threadIdx.x; e < m * p; e += DT) {
+                const int i = e / p, j = e % p;
+                double Jij = 0.0;
+                if (a.itg == RK_INTERROGATE_KRAMER && j % nd == 0) {
+                    const int v = j / nd;
+                    Jij = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+                }
+                w.Wt[e] = a.W[e] + (-Jij);
+            }
+            __syncthreads();
+        }
+        for (int i = threadIdx.x >> 6; i < m; i += DT / 64) {
+            const int lane = threadIdx.x & 63;
+            double s = 0.0, jm = 0.0, wm = 0.0;
+            if (MODE == 0)
+                for (int v = lane; v < m; v += 64) {
+                    const double Aiv = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+                    s = fma(Aiv, w.mup[(size_t)v * nd], s);
+                }
+            for (int j = lane; j < p; j += 64) {
+                const double wt = w.Wt[(size_t)i * p + j], mj = w.mup[j];
+                if (MODE == 0) jm = fma(a.W[(size_t)i * p + j] - wt, mj, jm);
+                wm = fma(wt, mj, wm);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); jm += __shfl_xor(jm, off); wm += __shfl_xor(wm, off); }
+            const double am = MODE != 0 ? w.f[i] : (a.itg == RK_INTERROGATE_KRAMER ? -s + jm : -s);
+            if (lane == 0) w.yhat[i] = wm + am;
+        }
+        __syncthreads();
+        // ---- update (square_root.py:88-99) ----
+        wg_gemm(gemm_op(w.WS, p, w.Wt, p, false, Lp, p, false, m, p, p, nullptr, 0, 0.0, 1.0));            // W~ L^-
+        wg_transpose(w.Sm, m, w.WS, p, p, m, 0);
+        if (noisy) {
+            // the reference hands W L^- W^T to the update as the "factor" of var_meas (interrogate.py:110-113 called with
+            // a factor): kept, it defines the reference's numbers in this mode
+            wg_gemm(gemm_op(w.Vh, m, w.WS, p, false, a.W, p, true, m, m, p, nullptr, 0, 0.0, 1.0));
+            wg_transpose(w.Sm + (size_t)p * m, m, w.Vh, m, m, m, 0);
+        }
+        wg_qr_r(w.Sm, m, p + kv, m);                                                                       // L_m^T in w.Sm
+        for (int e = threadIdx.x; e < m * p; e += DT) w.X[e] = w.Wt[e];
+        __syncthreads();
+        wg_tri_solve<true>(w.Sm, m, 1, w.X, p, m, p);                                                      // L_m^{-1} W~
+        wg_gemm(gemm_op(w.W2, p, w.X, p, false, Lp, p, false, m, p, p, nullptr, 0, 0.0, 1.0));             // . L^-
+        wg_gemm(gemm_op(w.X, p, w.W2, p, false, Lp, p, true, m, p, p, nullptr, 0, 0.0, 1.0));              // . L^-^T
+        wg_tri_solve<false>(w.Sm, m, 0, w.X, p, m, p);                                                     // L_m^{-T} . = K^T
+        for (int i = threadIdx.x; i < p; i += DT) {
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s = fma(w.X[(size_t)j * p + i], 0.0 - w.yhat[j], s);
+            mu_o[i] = w.mup[i] + s;
+        }
+        wg_gemm(gemm_op(w.A1, p, w.X, p, true, w.WS, p, false, p, p, m, Lp, p, 1.0, -1.0));                // L^- - K (W~ L^-)
+        wg_transpose(w.S, p, w.A1, p, p, p, 0);
+        if (noisy) wg_gemm(gemm_op(w.S + (size_t)p * p, p, w.Vh, m, true, w.X, p, false, m, p, m, nullptr, 0, 0.0, 1.0));   // (K V^{1/2})^T
+        wg_qr_r(w.S, p, p + kv, p);
+        wg_transpose(L_o, p, w.S, p, p, p, 1);
+    };
+    if (MODE == 0) {
+        for (int n = 0; n < a.N; ++n) { predict(n); update(n); }
+    } else if (MODE == 1) {
+        predict(0);
+    } else {
+        update(a.n0);
+        if (a.n0 + 1 < a.N) predict(a.n0 + 1);
+    }
+}
+
+// G^T = L^-^{-T} ( (L^-^{-1} Q) (L_f L_f^T) ) into w.A3 (square_root.py:170-175), mu- into w.mup
+__device__ __forceinline__ void dense_sqrt_gain(const DenseArgs& a, const DenseSqWs& w, const double* Lf, const double* Lp,
+                                                const double* mu_f, int p) {
+    wg_gemm(gemm_op(w.A1, p, Lf, p, false, Lf, p, true, p, p, p, nullptr, 0, 0.0, 1.0));                   // L_f L_f^T
+    for (int e = threadIdx.x; e < p * p; e += DT) w.A2[e] = a.Q[e];
+    __syncthreads();
+    wg_tri_solve<true>(Lp, p, 0, w.A2, p, p, p);                                                           // L^-^{-1} Q
+    wg_gemm(gemm_op(w.A3, p, w.A2, p, false, w.A1, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
+    wg_tri_solve<false>(Lp, p, 1, w.A3, p, p, p);                                                          // G^T
+    wg_gemv<false>(w.mup, a.Q, p, mu_f, p, p, nullptr, 0.0, 1.0);
+    // J^T = I - Q^T G^T into w.A1 (square_root.py:215-216)
+    wg_gemm(gemm_op(w.A1, p, a.Q, p, true, w.A3, p, false, p, p, p, nullptr, 0, 0.0, -1.0));
+    for (int i = threadIdx.x; i < p; i += DT) w.A1[(size_t)i * p + i] += 1.0;
+    __syncthreads();
+}
+// out = mu_f + G dm (column sums of G^T = w.A3 through LDS)
+__device__ __forceinline__ void dense_sqrt_mean(const DenseSqWs& w, const double* mu_f, double* out, int p) {
+    double* const lds = g_lds;
+    const int ng = DT / 64;
+    for (int i = threadIdx.x & 63; i < p; i += 64) {
+        const int gq = threadIdx.x >> 6;
+        double s = 0.0;
+#pragma unroll 8
+        for (int j = gq; j < p; j += ng) s = fma(w.A3[(size_t)j * p + i], w.dm[j], s);
+        lds[gq * p + i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p; i += DT) {
+        double s = 0.0;
+        for (int gq = 0; gq < ng; ++gq) s += lds[gq * p + i];
+        out[i] = mu_f[i] + s;
+    }
+    __syncthreads();
+}
+
+// Backward mean / variance smoother in square-root form (solve.py:257-301 with square_root.py:209-219), in place.
+__global__ void __launch_bounds__(DT) dense_sqrt_bwd_mv_kernel(DenseArgs a) {
+    const int b = blockIdx.x, p = a.p, m = a.m;
+    const DenseSqWs w = carve_sq(a.ws + (size_t)b * a.ws_stride, p, m);
+    double* mean = a.mean + (size_t)b * (a.N + 1) * p;
+    double* var = a.var + (size_t)b * (a.N + 1) * p * p;
+    const double* facp = a.fac_pred + (size_t)b * (a.N + 1) * p * p;
+    const size_t pp = (size_t)p * p;
+    for (int n = a.N - 1; n >= 1; --n) {
+        double* mu_f = mean + (size_t)n * p;
+        double* Lf = var + (size_t)n * pp;
+        const double* mu_s = mean + (size_t)(n + 1) * p;
+        const double* Ls = var + (size_t)(n + 1) * pp;
+        const double* Lp = facp + (size_t)(n + 1) * pp;
+        dense_sqrt_gain(a, w, Lf, Lp, mu_f, p);
+        for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = mu_s[i] - w.mup[i];
+        __syncthreads();
+        // L_s = add_sqrt(G [L_next | R^{1/2}], J L_f): rows of the stacked matrix = (G L_next)^T, (G R^{1/2})^T, (J L_f)^T
+        wg_gemm(gemm_op(w.S, p, Ls, p, true, w.A3, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
+        wg_gemm(gemm_op(w.S + pp, p, a.R, p, true, w.A3, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
+        wg_gemm(gemm_op(w.S + 2 * pp, p, Lf, p, true, w.A1, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
+        dense_sqrt_mean(w, mu_f, mu_f, p);                                                    // square_root.py:211-212
+        wg_qr_r(w.S, p, 3 * p, p);
+        wg_transpose(Lf, p, w.S, p, p, p, 1);
+    }
+}
+
+// x = mean + L (sgn . z) with L = R^T for the upper triangular R (row stride p) and sgn_j = sign of r_jj: the factor's
+// column signs are normalised (diagonal >= 0) so that the draw does not depend on the signs a QR happens to produce
+// (oracle/scan.py draw(), oracle/interrogations.py).  z: p standard normals at g_lds[zoff ..].
+__device__ __forceinline__ void dense_sqrt_draw(const double* R, const double* mean, double* x, int p, int zoff, bool lower) {
+    const double* const z = g_lds + zoff;
+    for (int i = threadIdx.x; i < p; i += DT) {
+        double acc = 0.0;
+        for (int j = 0; j <= i; ++j) {
+            const double d = lower ? R[(size_t)j * p + j] : R[(size_t)j * p + j];
+            const double lij = lower ? R[(size_t)i * p + j] : R[(size_t)j * p + i];
+            acc = fma(d < 0.0 ? -lij : lij, z[j], acc);
+        }
+        x[i] = mean[i] + acc;
+    }
+    __syncthreads();
+}
+
+// Backward sampler in square-root form (solve.py:137-205 with square_root.py:252-261); the filtered factors stay untouched.
+__global__ void __launch_bounds__(DT) dense_sqrt_bwd_sim_kernel(DenseArgs a) {
+    const int b = blockIdx.x, p = a.p, m = a.m;
+    const DenseSqWs w = carve_sq(a.ws + (size_t)b * a.ws_stride, p, m);
+    const double* mean = a.mean + (size_t)b * (a.N + 1) * p;
+    const double* var = a.var + (size_t)b * (a.N + 1) * p * p;
+    const double* facp = a.fac_pred + (size_t)b * (a.N + 1) * p * p;
+    const size_t pp = (size_t)p * p;
+    const unsigned traj = (unsigned)(a.traj_offset + (unsigned long long)b);
+    auto put_x = [&](int n, const double* xv) {
+        for (int i = threadIdx.x; i < p; i += DT) a.x[((size_t)n * p + i) * a.B + b] = xv[i];
+    };
+    double* const xn = w.W2;                                   // x_{n+1}: p doubles (w.W2 holds m p >= p and is free here)
+    wg_normals(a.seed, traj, (unsigned)a.N, PURPOSE_SMOOTH, p, 0);
+    dense_sqrt_draw(var + (size_t)a.N * pp, mean + (size_t)a.N * p, xn, p, 0, true);        // terminal draw (solve.py:182-186)
+    put_x(a.N, xn);
+    __syncthreads();
+    for (int n = a.N - 1; n >= 1; --n) {
+        const double* mu_f = mean + (size_t)n * p;
+        const double* Lf = var + (size_t)n * pp;
+        const double* Lp = facp + (size_t)(n + 1) * pp;
+        dense_sqrt_gain(a, w, Lf, Lp, mu_f, p);
+        for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = xn[i] - w.mup[i];                 // x_{n+1} - mu-
+        __syncthreads();
+        wg_gemm(gemm_op(w.S, p, a.R, p, true, w.A3, p, false, p, p, p, nullptr, 0, 0.0, 1.0));              // (G R^{1/2})^T
+        wg_gemm(gemm_op(w.S + pp, p, Lf, p, true, w.A1, p, false, p, p, p, nullptr, 0, 0.0, 1.0));          // (J L_f)^T
+        dense_sqrt_mean(w, mu_f, w.mup, p);                                                   // mean_sim (square_root.py:254-255)
+        wg_qr_r(w.S, p, 2 * p, p);
+        wg_normals(a.seed, traj, (unsigned)n, PURPOSE_SMOOTH, p, 0);
+        dense_sqrt_draw(w.S, w.mup, xn, p, 0, false);
+        put_x(n, xn);
+        __syncthreads();
+    }
+    put_x(0, mean);
+}
+
+}  // namespace rk

@@ -577,7 +577,7 @@ static int launch_itg_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a
 bool dense_supported(const rk_solve_cfg* c, int mode);
 int dense_check(const rk_solve_cfg* c, const rk_solve_in* in, int mode);
 int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out, int mode);
-size_t dense_ws_doubles(int p, int m);
+size_t dense_ws_bytes(const rk_solve_cfg* c, int mode);
 
 // user-supplied right-hand sides (rhs_jit.hip)
 bool is_user_rhs(int rhs_id);
@@ -623,7 +623,7 @@ int rk_solve_layout(const rk_solve_cfg* c, int32_t mode, int32_t* layout) {
 
 int rk_solve_workspace_bytes(const rk_solve_cfg* c, int32_t mode, size_t* bytes) {
     RK_REQUIRE(c && bytes, RK_ERR_INVALID, "rk_solve_workspace_bytes: null argument");
-    if (dense_supported(c, mode)) *bytes = dense_ws_doubles(c->n_bstate, c->n_bmeas) * (size_t)c->n_traj * sizeof(double);
+    if (dense_supported(c, mode)) *bytes = dense_ws_bytes(c, mode);
     else if (!tile3_supported(c, mode) && !tile4_supported(c, mode) && tilen_supported(c, mode))
         *bytes = tilen_ws_doubles(c, mode) * sizeof(double);
     else *bytes = 0;

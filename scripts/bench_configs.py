@@ -75,11 +75,13 @@ def c5(args):
     Wb, _ = ra.utils.first_order_pad(lambda x, t: x, n_vars, n_deriv)
     W = block_diag(*[w for w in Wb])[None]
     prior = ra.indep_init(ra.ibm_init(1.0 / 2000, n_deriv, np.ones(n_vars)))
+    if args.c5_kalman == "square-root":
+        prior = (prior[0], np.linalg.cholesky(prior[1]))
     x0v = 1.0 + 0.01 * rng.standard_normal((B, n_vars))
     X0 = np.zeros((B, n_vars, n_deriv)); X0[..., 0] = x0v; X0[..., 1] = x0v @ A.T
     X0 = X0.reshape(B, 1, -1)
     plan = ra.SolvePlan(ra.ode.linear_dense(n_vars, n_deriv), W, X0, 0.0, N / 2000.0, N,
-                        getattr(ra.interrogate, "interrogate_" + args.c5_itg), prior, A=A)
+                        getattr(ra.interrogate, "interrogate_" + args.c5_itg), prior, kalman_type=args.c5_kalman, A=A)
     dev = plan.dev
     dev.profile_enable(True)
     t0 = time.perf_counter(); plan.mv(None); dev.sync(); wall = time.perf_counter() - t0
@@ -97,7 +99,12 @@ def c5(args):
         names = ["predict+T+diff", "LU panel", "LU swaps", "LU trsm", "LU gemm", "back trsm", "back gemm", "mean", "G D", "GDG^T"]
         cyc = ws[0, -2:-12:-1] / (N - 1)            # library built with -DRK_DENSE_STAMPS (solve_dense.hip)
         print("bwd phase cycles per step (wg 0):", {k: int(v) for k, v in zip(names, cyc)}, "total", int(cyc.sum()), file=sys.stderr)
-    return {"config": f"C5 dense p=160 m=32 N={N} B={B} solve_mv+{args.c5_itg}", "ms": ms, "kernels_ms": prof,
+    err = None
+    if args.c5_check:                                   # distance of trajectory 0's solution estimate from expm(A t) x0 at the last step
+        from scipy.linalg import expm
+        err = float(np.max(np.abs(plan.mean_state.slice0_host(0)[N, 0, ::n_deriv] - expm(A * N / 2000.0) @ x0v[0])))
+    return {"config": f"C5 dense p=160 m=32 N={N} B={B} solve_mv+{args.c5_itg} kalman_type={args.c5_kalman}", "ms": ms,
+            "kernels_ms": prof, "flop_count": "covariance form (SURVEY 8d)", "abs_err_vs_expm_last_step_traj0": err,
             "traj_steps_per_s": B * N / ms * 1e3, "tflops": F * B * N / (ms * 1e-3) / 1e12,
             "frac_fp64_peak_78.6TF": F * B * N / (ms * 1e-3) / 78.6e12, "wall_s": wall}
 
@@ -108,6 +115,8 @@ if __name__ == "__main__":
     ap.add_argument("--c5-batch", type=int, default=256)
     ap.add_argument("--c5-steps", type=int, default=2000)      # BASELINE config 5: N = 2000
     ap.add_argument("--c5-itg", default="kramer", choices=["kramer", "rodeo", "schober"])
+    ap.add_argument("--c5-kalman", default="standard", choices=["standard", "square-root"])
+    ap.add_argument("--c5-check", action="store_true")
     args = ap.parse_args()
     for w in args.which:
         print(json.dumps({"c3": c3, "c4": c4, "c5": c5}[w](args)), flush=True)

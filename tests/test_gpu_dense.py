@@ -76,10 +76,12 @@ def test_dense_matches_exact_solution_and_api(ra):
     assert m.shape == (N + 1, 1, n_vars * n_deriv) and v.shape == (N + 1, 1, n_vars * n_deriv, n_vars * n_deriv)
     exact = expm(s["A"] * t_max) @ s["x0v"]
     assert np.max(np.abs(m[-1, 0, ::n_deriv] - exact)) < 1e-3
-    from rodeo_amd._lib import RodeoKalmanError
-    with pytest.raises(RodeoKalmanError):                      # the dense path has no square-root form
-        ra.solve_mv(None, ra.ode.linear_dense(n_vars, n_deriv), s["W"], s["x0"], 0.0, t_max, N,
-                    ra.interrogate.interrogate_kramer, s["prior"], kalman_type="square-root", A=s["A"])
+    # the same posterior through the square-root form (tests/test_gpu_dense_sqrt.py holds its parity tests)
+    Q, R = s["prior"]
+    m2, L2 = ra.solve_mv(None, ra.ode.linear_dense(n_vars, n_deriv), s["W"], s["x0"], 0.0, t_max, N,
+                         ra.interrogate.interrogate_kramer, (Q, np.linalg.cholesky(R)), kalman_type="square-root", A=s["A"])
+    assert m2.shape == m.shape and L2.shape == v.shape
+    assert np.max(np.abs(m2[-1, 0, ::n_deriv] - exact)) < 1e-3
 
 
 def test_config5_full_size_properties(ra):
