@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librodeo_kalman.so")
+# RK_LIB_PATH: another build of the SAME library (the phase-timing build `make -C rodeo_amd/csrc stamps`); there is still no
+# fallback -- a path that does not load raises.
+LIB_PATH = os.environ.get("RK_LIB_PATH") or os.path.join(_HERE, "librodeo_kalman.so")
 
 RK_OK = 0
 RK_ERR_INVALID, RK_ERR_UNSUPPORTED, RK_ERR_HIP, RK_ERR_RCCL, RK_ERR_NOMEM = -1, -2, -3, -4, -5

@@ -68,7 +68,9 @@ constexpr int DT = 512, NWAVE = DT / 64;
 #define RK_STAMP(k) do { __syncthreads(); if (stamps_ && blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); stamps_[-2 - (k)] += (double)(t_ - stamp_t_); stamp_t_ = t_; } } while (0)
 #define RK_STAMP_RESET() stamp_t_ = __builtin_amdgcn_s_memtime()
 #define RK_STAMP_ZERO() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 12; ++k_) stamps_[-2 - k_] = 0.0; __syncthreads(); } while (0)
+#define RK_STAMP_ZERO_N(n_) do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < (n_); ++k_) stamps_[-2 - k_] = 0.0; __syncthreads(); } while (0)
 #else
+#define RK_STAMP_ZERO_N(n_)
 #define RK_STAMP_DECL(ws_end)
 #define RK_STAMP(k)
 #define RK_STAMP_RESET()

@@ -73,24 +73,45 @@ __device__ __noinline__ void wg_transpose(double* dst_, int ldd_, const double* 
 
 // ---------------------------------------------------------------------------------------------------------------
 // Panel factorisation (see the file header).  Thread t: column c = t & 15 of slab s = t >> 4; tri[i] = panel row i
-// (i < 16, replicated over the slabs), tall[i] = panel row 16 + s + 32 i.
+// (i < 16, replicated over the slabs), tall[i] = panel row 16 + s + 32 i.  Cross-lane traffic stays in the VALU: the
+// pivot column reaches the 16 lanes of a slab by DPP row_newbcast (gfx90a+), the triangle rows by v_readlane, the four
+// slabs of a wave are summed with v_permlane32_swap / v_permlane16_swap (gfx950); only the sum over the eight waves
+// goes through LDS (one barrier per column, buffers alternate).  The pivot lane keeps its column UNSCALED (nothing reads
+// it again) and remembers its own scale factor: no per-element selects in the update, V = x * scale at write-out.
 // ---------------------------------------------------------------------------------------------------------------
 template <int J>
-__device__ __forceinline__ void qr_panel_col(double (&tr)[16], double (&ta)[QR_RT], int c, int src_addr, int wave, int lane,
+__device__ __forceinline__ double row_bcast_f64(double x) {           // lane J of every 16-lane row to its whole row
+    int lo_ = __double2loint(x), hi_ = __double2hiint(x);
+    lo_ = __builtin_amdgcn_mov_dpp(lo_, 0x150 + J, 0xF, 0xF, false);       // (no `old` operand: every lane has a source)
+    hi_ = __builtin_amdgcn_mov_dpp(hi_, 0x150 + J, 0xF, 0xF, false);
+    return __hiloint2double(hi_, lo_);
+}
+__device__ __forceinline__ double slab_sum(double x) {                // x(l) + x(l^16) + x(l^32) + x(l^48), in every lane
+    unsigned lo_ = __double2loint(x), hi_ = __double2hiint(x);
+    auto a = __builtin_amdgcn_permlane32_swap(lo_, lo_, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi_, hi_, false, false);
+    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo_ = __double2loint(x); hi_ = __double2hiint(x);
+    a = __builtin_amdgcn_permlane16_swap(lo_, lo_, false, false);
+    b = __builtin_amdgcn_permlane16_swap(hi_, hi_, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+template <int RT, int J>
+__device__ __forceinline__ void qr_panel_col(double (&tr)[16], double (&ta)[RT], double& myscale, int c, int wave, int lane,
                                              int pg_off, int tau_off) {
-    // the pivot column: triangle rows from lane J (every slab holds them), the slab's tall rows from lane (slab, J)
-    double pt[16], pu[QR_RT];
+    double pt[16], pu[RT];
 #pragma unroll
     for (int i = J; i < 16; ++i) pt[i] = readlane_f64(tr[i], J);
 #pragma unroll
-    for (int i = 0; i < QR_RT; ++i) pu[i] = bperm_f64(ta[i], src_addr);
+    for (int i = 0; i < RT; ++i) pu[i] = row_bcast_f64<J>(ta[i]);
     double gt = 0.0, nt = 0.0, gu = 0.0, nu = 0.0;
 #pragma unroll
     for (int i = J + 1; i < 16; ++i) { gt = fma(pt[i], tr[i], gt); nt = fma(pt[i], pt[i], nt); }
 #pragma unroll
-    for (int i = 0; i < QR_RT; ++i) { gu = fma(pu[i], ta[i], gu); nu = fma(pu[i], pu[i], nu); }
-    gu += __shfl_xor(gu, 16); nu += __shfl_xor(nu, 16);
-    gu += __shfl_xor(gu, 32); nu += __shfl_xor(nu, 32);
+    for (int i = 0; i < RT; ++i) { gu = fma(pu[i], ta[i], gu); nu = fma(pu[i], pu[i], nu); }
+    gu = slab_sum(gu);
+    nu = slab_sum(nu);
     double* const bb = g_lds + pg_off + (J & 1) * 136;  // [c][wave] partial dots, then [wave] partial norms
     if (lane < 16) bb[c * 8 + wave] = gu;
     if (lane == 0) bb[128 + wave] = nu;
@@ -102,58 +123,64 @@ __device__ __forceinline__ void qr_panel_col(double (&tr)[16], double (&ta)[QR_R
     const double alpha = pt[J], xn2 = nt + Nn;
     const bool refl = xn2 != 0.0;
     const double beta = refl ? -copysign(sqrt(fma(alpha, alpha, xn2)), alpha) : alpha;
-    const double tau = refl ? (beta - alpha) / beta : 0.0;
-    const double scale = refl ? 1.0 / (alpha - beta) : 0.0;
+    const double tau = refl ? (beta - alpha) * fast_rcp(beta) : 0.0;
+    const double scale = refl ? fast_rcp(alpha - beta) : 0.0;
     if (threadIdx.x == 0) g_lds[tau_off + J] = tau;
-    // w_c = tau (a_Jc + v_below . a_c) for the columns right of J; column J itself becomes (beta, v)
+    // w_c = tau (a_Jc + v_below . a_c) for the columns right of J;  a_c <- a_c - v w_c with v = x scale
     const bool right = c > J, piv = c == J;
     const double wc = right ? tau * fma(scale, gt + G, tr[J]) : 0.0;
+    myscale = piv ? scale : myscale;
     tr[J] = piv ? beta : tr[J] - wc;
+    const double z = -(scale * wc);
 #pragma unroll
-    for (int i = J + 1; i < 16; ++i) { const double v = pt[i] * scale; tr[i] = piv ? v : fma(-v, wc, tr[i]); }
+    for (int i = J + 1; i < 16; ++i) tr[i] = fma(pt[i], z, tr[i]);
 #pragma unroll
-    for (int i = 0; i < QR_RT; ++i) { const double v = pu[i] * scale; ta[i] = piv ? v : fma(-v, wc, ta[i]); }
+    for (int i = 0; i < RT; ++i) ta[i] = fma(pu[i], z, ta[i]);
 }
-template <int J>
-__device__ __forceinline__ void qr_panel_cols(double (&tr)[16], double (&ta)[QR_RT], int c, int src_base, int wave, int lane,
+template <int RT, int J>
+__device__ __forceinline__ void qr_panel_cols(double (&tr)[16], double (&ta)[RT], double& myscale, int c, int wave, int lane,
                                               int nb, int pg_off, int tau_off) {
     if constexpr (J < 16) {
-        if (J < nb) qr_panel_col<J>(tr, ta, c, src_base + 4 * J, wave, lane, pg_off, tau_off);
+        if (J < nb) qr_panel_col<RT, J>(tr, ta, myscale, c, wave, lane, pg_off, tau_off);
         else if (threadIdx.x == 0) g_lds[tau_off + J] = 0.0;
-        qr_panel_cols<J + 1>(tr, ta, c, src_base, wave, lane, nb, pg_off, tau_off);
+        qr_panel_cols<RT, J + 1>(tr, ta, myscale, c, wave, lane, nb, pg_off, tau_off);
     }
 }
 
-// Factors the panel P (Mk rows, nb <= 16 columns, row stride ld, in global memory): R11's upper triangle back to P, V (unit
-// lower trapezoid, explicit ones and zeros) to the LDS panel g_lds[r * LU_LD + c], tau to g_lds[tau_off ..].
-__device__ __noinline__ void qr_panel(double* P_, int ld_, int Mk_, int nb_, int pg_off_, int tau_off_) {
+// Factors the panel P (Mk <= 16 + 32 RT rows, nb <= 16 columns, row stride ld, in global memory): R11's upper triangle back
+// to P, V (unit lower trapezoid, explicit ones and zeros) to the LDS panel g_lds[r * LU_LD + c], tau to g_lds[tau_off ..].
+template <int RT>
+__device__ __forceinline__ void qr_panel_body(double* P_, int ld_, int Mk_, int nb_, int pg_off_, int tau_off_) {
     auto* const P = uni_g(P_);
     const int ld = uni(ld_), Mk = uni(Mk_), nb = uni(nb_), pg_off = uni(pg_off_), tau_off = uni(tau_off_);
     const int tid = threadIdx.x, c = tid & 15, s = tid >> 4, lane = tid & 63, wave = uni((int)(tid >> 6));
-    double tr[16], ta[QR_RT];
+    double tr[16], ta[RT], myscale = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) tr[i] = (c < nb && i < Mk) ? P[(size_t)i * ld + c] : 0.0;
 #pragma unroll
-    for (int i = 0; i < QR_RT; ++i) {
+    for (int i = 0; i < RT; ++i) {
         const int r = 16 + s + 32 * i;
         ta[i] = (c < nb && r < Mk) ? P[(size_t)r * ld + c] : 0.0;
     }
-    qr_panel_cols<0>(tr, ta, c, 4 * (lane & 48), wave, lane, nb, pg_off, tau_off);
+    qr_panel_cols<RT, 0>(tr, ta, myscale, c, wave, lane, nb, pg_off, tau_off);
     double* const panel = g_lds;
     if (s == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (i < Mk) panel[i * LU_LD + c] = i > c ? tr[i] : ((i == c && c < nb) ? 1.0 : 0.0);
+            if (i < Mk) panel[i * LU_LD + c] = i > c ? tr[i] * myscale : ((i == c && c < nb) ? 1.0 : 0.0);
             if (i <= c && c < nb && i < Mk) P[(size_t)i * ld + c] = tr[i];
         }
     }
 #pragma unroll
-    for (int i = 0; i < QR_RT; ++i) {
+    for (int i = 0; i < RT; ++i) {
         const int r = 16 + s + 32 * i;
-        if (r < Mk) panel[r * LU_LD + c] = ta[i];
+        if (r < Mk) panel[r * LU_LD + c] = ta[i] * myscale;
     }
+    for (int e = tid; e < (((Mk + 15) & ~15) - Mk) * 16; e += DT) panel[(Mk + (e >> 4)) * LU_LD + (e & 15)] = 0.0;   // whole tiles
     __syncthreads();
 }
+__device__ __noinline__ void qr_panel7(double* P, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<7>(P, ld, Mk, nb, pg_off, tau_off); }
+__device__ __noinline__ void qr_panel15(double* P, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<QR_RT>(P, ld, Mk, nb, pg_off, tau_off); }
 
 // T (16 x 16 upper triangular, g_lds[t_off + i * 16 + j]) of the compact WY form from the LDS panel V and tau:
 // T_jj = tau_j, T(0:j, j) = -tau_j T(0:j, 0:j) (V^T V)(0:j, j)   (LAPACK dlarft, forward / columnwise).
@@ -195,62 +222,93 @@ __device__ __noinline__ void qr_build_T(int Mk_, int gp_off_, int t_off_, int ta
     }
 }
 
-// W (16 x n2, LDS strip us[k * usp + j]) = V^T A2, A2 = the Mk x n2 matrix right of the panel (global, row stride lda):
-// wave w owns the column tiles w, w + 8, ...; per 4 rows one MFMA with the A fragment from the LDS panel and the B
-// fragment straight from memory (the next group's loads are issued before the current group's MFMAs).
-__device__ __noinline__ void qr_w_pass(const double* A2_, int lda_, int Mk_, int n2_, int us_off_, int usp_) {
+// A2 <- (I - V T^T V^T) A2 for the Mk x n2 matrix right of the panel, ONE pass over memory: a unit = (column tile, half of
+// the row tiles); the two halves of a column tile run in the same round on neighbouring waves.  A wave loads its (up to
+// 16) tiles of 16 x 16 into registers -- the loaded tile IS the B fragment of W = V^T A2 (v_mfma_f64_16x16x4: register
+// v of a tile holds its rows 4v .. 4v+3) -- accumulates its half of W, exchanges the halves through LDS (one barrier
+// per round, buffers alternate), forms W' = T^T W with four MFMAs (W's accumulator is again a B fragment), applies
+// tile -= V_rows W' onto the registers it still holds and stores them: every element of A2 is read once and written once.
+constexpr int QF_T = 16;                                // row tiles per unit: panels of up to 512 rows
+__device__ __noinline__ void qr_fused_update(double* A2_, int lda_, int Mk_, int n2_, int t_off_, int px_off_) {
     auto* const A2 = uni_g(A2_);
-    const int lda = uni(lda_), Mk = uni(Mk_), n2 = uni(n2_), usp = uni(usp_);
-    const double* const panel = g_lds;
-    double* const us = g_lds + uni(us_off_);
+    const int lda = uni(lda_), Mk = uni(Mk_), n2 = uni(n2_), t_off = uni(t_off_), px_off = uni(px_off_);
+    const double* const panel = g_lds;                                // rows Mk .. 16 nrt - 1 are zero (qr_panel_body)
+    const double* const T = g_lds + t_off;
     const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
-    const int nct = (n2 + 15) >> 4;
-    constexpr int UB = 8;
-    for (int ct = wave; ct < nct; ct += NWAVE) {
+    const int nct = (n2 + 15) >> 4, nrt = (Mk + 15) >> 4, h0 = (nrt + 1) >> 1;
+    const int rounds = (2 * nct + NWAVE - 1) / NWAVE;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int u = rd * NWAVE + wave;                              // (scalar: wave is)
+        const bool live = u < 2 * nct;
+        const int ct = u >> 1, half = u & 1;
+        const int rb0 = half ? h0 : 0, nq = live ? (half ? nrt - h0 : h0) : 0;
         const int j = ct * 16 + lo;
-        const bool cok = j < n2;
-        auto load = [&](int r0, double (&b)[UB]) {
+        const bool cok = live && j < n2;
+        double* const px = g_lds + px_off + (rd & 1) * (NWAVE * 256);
+        // Addresses: a scalar row-tile base plus four per-lane offsets (rows 4v + hi of a tile, column j).  No load is
+        // masked (a select behind a load makes hipcc wait for that load at once): a row past the end reads the last row,
+        // a column past the end column 0 -- finite values of the matrix that meet zero rows of V and are never stored.
+        gd* const base = A2 + (size_t)(16 * rb0) * lda;
+        const int rows_left = Mk - 16 * rb0;
+        const int jc = cok ? j : 0;
+        int voff[4];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int r = r0 + 4 * u + hi;
-                b[u] = (cok && r < Mk) ? A2[(size_t)r * lda + j] : 0.0;
+        for (int v = 0; v < 4; ++v) voff[v] = (4 * v + hi) * lda + jc;
+        d4 t[QF_T];
+#pragma unroll
+        for (int q = 0; q < QF_T; ++q) {
+            if (q < nq) {
+                gd* const tb = base + (size_t)(16 * q) * lda;                  // scalar
+                const int rl = rows_left - 16 * q;                            // rows of this tile that exist (>= 1)
+                if (rl >= 16) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) t[q][v] = tb[voff[v]];
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) t[q][v] = tb[min(4 * v + hi, rl - 1) * lda + jc];
+                }
             }
-        };
+        }
         d4 acc = d4{0, 0, 0, 0};
-        double cur[UB], nxt[UB];
-        load(0, cur);
-        for (int r0 = 0; r0 < Mk; r0 += 4 * UB) {
-            load(r0 + 4 * UB, nxt);
+        const double* const pb = panel + 16 * rb0 * LU_LD + hi * LU_LD + lo;          // V^T fragments: [16 q + 4 v + hi][lo]
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int r = r0 + 4 * u + hi;
-                const double a = r < Mk ? panel[r * LU_LD + lo] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, cur[u], acc, 0, 0, 0);
+        for (int q = 0; q < QF_T; ++q) {
+            if (q < nq) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[(16 * q + 4 * v) * LU_LD], t[q][v], acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) cur[u] = nxt[u];
         }
+        if (live) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) us[(4 * v + hi) * usp + ct * 16 + lo] = acc[v];
-    }
-}
-
-// W <- T^T W in the LDS strip, one thread per column
-__device__ __forceinline__ void qr_apply_T(int ncols, double* us, int usp, const double* T) {
-    for (int c = threadIdx.x; c < ncols; c += DT) {
-        double w[16], o[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) w[k] = us[k * usp + c];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int k = 0; k <= i; ++k) sacc = fma(T[k * 16 + i], w[k], sacc);
-            o[i] = sacc;
+            for (int v = 0; v < 4; ++v) px[wave * 256 + (4 * v + hi) * 16 + lo] = acc[v];
         }
+        __syncthreads();
+        if (live) {
+            d4 wsum, wp = d4{0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) us[i * usp + c] = o[i];
+            for (int v = 0; v < 4; ++v)
+                wsum[v] = px[(wave & ~1) * 256 + (4 * v + hi) * 16 + lo] + px[(wave | 1) * 256 + (4 * v + hi) * 16 + lo];
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq)                                    // W' = T^T W
+                wp = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(4 * kq + hi) * 16 + lo], wsum[kq], wp, 0, 0, 0);
+            const double* const eb = panel + 16 * rb0 * LU_LD + lo * LU_LD + hi;      // V fragments: [16 q + lo][4 kq + hi]
+#pragma unroll
+            for (int q = 0; q < QF_T; ++q) {
+                if (q < nq) {
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+                        t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-eb[16 * q * LU_LD + 4 * kq], wp[kq], t[q], 0, 0, 0);
+                    gd* const tb = base + (size_t)(16 * q) * lda;
+                    const int rl = rows_left - 16 * q;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (cok && 4 * v + hi < rl) tb[voff[v]] = t[q][v];
+                }
+            }
+        }
     }
+    __syncthreads();
 }
 
 // Fallback beyond the LDS panel's limits: column-by-column Householder in global memory (one wave per trailing column).
@@ -291,26 +349,26 @@ __device__ __noinline__ void wg_qr_r_unblocked(double* S_, int ld_, int M_, int 
 
 // In place: the upper triangle of the top n x n block of S (M x n, row stride ld, M >= 1) becomes the R of S's QR
 // factorisation (LAPACK's sign convention: r_jj = -sign(a_jj) ||.||); everything below the diagonal is left undefined.
-__device__ __noinline__ void wg_qr_r(double* S_, int ld_, int M_, int n_) {
+__device__ __noinline__ void wg_qr_r(double* S_, int ld_, int M_, int n_, double* ws_end_ = nullptr) {
     auto* const S = uni_g(S_);
+    auto* const ws_end = uni_g(ws_end_);
+    (void)ws_end;
     const int ld = uni(ld_), M = uni(M_), n = uni(n_);
-    const int npad = (n + 15) & ~15;
-    const int us_off = M * LU_LD, usp = (npad + 16) | 1;
-    const int gp_off = us_off + 16 * usp, t_off = gp_off + NWAVE * 256, tau_off = t_off + 256, pg_off = tau_off + 16;
-    if (M > QR_MAXM || pg_off + 2 * 136 > LDS_DOUBLES) { wg_qr_r_unblocked((double*)S, ld, M, n); return; }
+    RK_STAMP_DECL(ws_end);
+    const int gp_off = (((M + 15) & ~15) * LU_LD + 1) & ~1, t_off = gp_off + NWAVE * 256, tau_off = t_off + 256, pg_off = tau_off + 16;
+    const int px_off = pg_off + 2 * 136;                // partial W tiles of the fused update: 2 x 8 x 256
+    if (M > QR_MAXM || px_off + 2 * NWAVE * 256 > LDS_DOUBLES) { wg_qr_r_unblocked((double*)S, ld, M, n); return; }
     __syncthreads();
     for (int k0 = 0; k0 < n && k0 < M; k0 += 16) {
         const int nb = min(16, n - k0), Mk = M - k0, n2 = n - k0 - nb;
-        qr_panel((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
+        if (Mk <= 16 + 32 * 7) qr_panel7((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
+        else qr_panel15((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
+        RK_STAMP(10);
         if (n2 > 0) {
             qr_build_T(Mk, gp_off, t_off, tau_off);
-            qr_w_pass((const double*)(S + (size_t)k0 * ld + k0 + nb), ld, Mk, n2, us_off, usp);
-            __syncthreads();
-            qr_apply_T((n2 + 15) & ~15, g_lds + us_off, usp, g_lds + t_off);
-            __syncthreads();
-            lu_rank_update(0, Mk, 16, us_off, usp, (Mk + 15) >> 4, (double*)(S + (size_t)k0 * ld + k0 + nb), ld, n2, (n2 + 15) >> 4,
-                           (double*)(S + (size_t)k0 * ld + k0 + nb), ld, 0, 0, 0, Mk);
-            __syncthreads();
+            RK_STAMP(11);
+            qr_fused_update((double*)(S + (size_t)k0 * ld + k0 + nb), ld, Mk, n2, t_off, px_off);
+            RK_STAMP(13);
         }
     }
 }
@@ -503,7 +561,11 @@ __global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
     const double* Aode = a.theta;
     const bool noisy = a.itg == RK_INTERROGATE_RODEO;              // var_meas != 0 (interrogate.py:110-113)
     const int kv = noisy ? m : 0;
+    double* const ws_end = a.ws + a.ws_stride;                     // (phase stamps of workgroup 0, -DRK_DENSE_STAMPS)
+    (void)ws_end;
+    RK_STAMP_DECL(ws_end);
     if (MODE != 2) {
+        RK_STAMP_ZERO_N(15);
         for (int i = threadIdx.x; i < p; i += DT) mean[i] = a.x0_b ? a.x0[(size_t)i * a.B + b] : a.x0[i];
         for (int e = threadIdx.x; e < p * p; e += DT) var[e] = 0.0;
         if (facp) for (int e = threadIdx.x; e < p * p; e += DT) facp[e] = 0.0;
@@ -515,11 +577,15 @@ __global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
         const double* Ln = var + (size_t)n * p * p;
         double* Lp = facp ? facp + (size_t)(n + 1) * p * p : w.A2;
         // square_root.py:56-57: L^- = add_sqrt(Q L, R^{1/2}) = R^T of qr([ (Q L)^T ; R^{1/2 T} ])
+        RK_STAMP_RESET();
         wg_gemm(gemm_op(w.S, p, Ln, p, true, a.Q, p, true, p, p, p, nullptr, 0, 0.0, 1.0));
         wg_transpose(w.S + (size_t)p * p, p, a.R, p, p, p, 0);
-        wg_qr_r(w.S, p, 2 * p, p);
+        RK_STAMP(0);
+        wg_qr_r(w.S, p, 2 * p, p, ws_end);
+        RK_STAMP(1);
         wg_transpose(Lp, p, w.S, p, p, p, 1);
         wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);
+        RK_STAMP(2);
         if (meanp) {
             for (int i = threadIdx.x; i < p; i += DT) meanp[(size_t)(n + 1) * p + i] = w.mup[i];
             __syncthreads();
@@ -562,6 +628,7 @@ __global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
         }
         __syncthreads();
         // ---- update (square_root.py:88-99) ----
+        RK_STAMP(3);
         wg_gemm(gemm_op(w.WS, p, w.Wt, p, false, Lp, p, false, m, p, p, nullptr, 0, 0.0, 1.0));            // W~ L^-
         wg_transpose(w.Sm, m, w.WS, p, p, m, 0);
         if (noisy) {
@@ -570,13 +637,18 @@ __global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
             wg_gemm(gemm_op(w.Vh, m, w.WS, p, false, a.W, p, true, m, m, p, nullptr, 0, 0.0, 1.0));
             wg_transpose(w.Sm + (size_t)p * m, m, w.Vh, m, m, m, 0);
         }
+        RK_STAMP(4);
         wg_qr_r(w.Sm, m, p + kv, m);                                                                       // L_m^T in w.Sm
+        RK_STAMP(5);
         for (int e = threadIdx.x; e < m * p; e += DT) w.X[e] = w.Wt[e];
         __syncthreads();
         wg_tri_solve<true>(w.Sm, m, 1, w.X, p, m, p);                                                      // L_m^{-1} W~
+        RK_STAMP(6);
         wg_gemm(gemm_op(w.W2, p, w.X, p, false, Lp, p, false, m, p, p, nullptr, 0, 0.0, 1.0));             // . L^-
         wg_gemm(gemm_op(w.X, p, w.W2, p, false, Lp, p, true, m, p, p, nullptr, 0, 0.0, 1.0));              // . L^-^T
+        RK_STAMP(7);
         wg_tri_solve<false>(w.Sm, m, 0, w.X, p, m, p);                                                     // L_m^{-T} . = K^T
+        RK_STAMP(6);
         for (int i = threadIdx.x; i < p; i += DT) {
             double s = 0.0;
             for (int j = 0; j < m; ++j) s = fma(w.X[(size_t)j * p + i], 0.0 - w.yhat[j], s);
@@ -585,8 +657,11 @@ __global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
         wg_gemm(gemm_op(w.A1, p, w.X, p, true, w.WS, p, false, p, p, m, Lp, p, 1.0, -1.0));                // L^- - K (W~ L^-)
         wg_transpose(w.S, p, w.A1, p, p, p, 0);
         if (noisy) wg_gemm(gemm_op(w.S + (size_t)p * p, p, w.Vh, m, true, w.X, p, false, m, p, m, nullptr, 0, 0.0, 1.0));   // (K V^{1/2})^T
-        wg_qr_r(w.S, p, p + kv, p);
+        RK_STAMP(8);
+        wg_qr_r(w.S, p, p + kv, p, ws_end);
+        RK_STAMP(9);
         wg_transpose(L_o, p, w.S, p, p, p, 1);
+        RK_STAMP(2);
     };
     if (MODE == 0) {
         for (int n = 0; n < a.N; ++n) { predict(n); update(n); }
@@ -601,17 +676,25 @@ __global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
 // G^T = L^-^{-T} ( (L^-^{-1} Q) (L_f L_f^T) ) into w.A3 (square_root.py:170-175), mu- into w.mup
 __device__ __forceinline__ void dense_sqrt_gain(const DenseArgs& a, const DenseSqWs& w, const double* Lf, const double* Lp,
                                                 const double* mu_f, int p) {
+    double* const ws_end = a.ws + a.ws_stride;
+    (void)ws_end;
+    RK_STAMP_DECL(ws_end);
     wg_gemm(gemm_op(w.A1, p, Lf, p, false, Lf, p, true, p, p, p, nullptr, 0, 0.0, 1.0));                   // L_f L_f^T
     for (int e = threadIdx.x; e < p * p; e += DT) w.A2[e] = a.Q[e];
     __syncthreads();
+    RK_STAMP(0);
     wg_tri_solve<true>(Lp, p, 0, w.A2, p, p, p);                                                           // L^-^{-1} Q
+    RK_STAMP(1);
     wg_gemm(gemm_op(w.A3, p, w.A2, p, false, w.A1, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
+    RK_STAMP(2);
     wg_tri_solve<false>(Lp, p, 1, w.A3, p, p, p);                                                          // G^T
+    RK_STAMP(3);
     wg_gemv<false>(w.mup, a.Q, p, mu_f, p, p, nullptr, 0.0, 1.0);
     // J^T = I - Q^T G^T into w.A1 (square_root.py:215-216)
     wg_gemm(gemm_op(w.A1, p, a.Q, p, true, w.A3, p, false, p, p, p, nullptr, 0, 0.0, -1.0));
     for (int i = threadIdx.x; i < p; i += DT) w.A1[(size_t)i * p + i] += 1.0;
     __syncthreads();
+    RK_STAMP(4);
 }
 // out = mu_f + G dm (column sums of G^T = w.A3 through LDS)
 __device__ __forceinline__ void dense_sqrt_mean(const DenseSqWs& w, const double* mu_f, double* out, int p) {
@@ -641,6 +724,10 @@ __global__ void __launch_bounds__(DT) dense_sqrt_bwd_mv_kernel(DenseArgs a) {
     double* var = a.var + (size_t)b * (a.N + 1) * p * p;
     const double* facp = a.fac_pred + (size_t)b * (a.N + 1) * p * p;
     const size_t pp = (size_t)p * p;
+    double* const ws_end = a.ws + a.ws_stride;
+    (void)ws_end;
+    RK_STAMP_DECL(ws_end);
+    RK_STAMP_ZERO_N(15);
     for (int n = a.N - 1; n >= 1; --n) {
         double* mu_f = mean + (size_t)n * p;
         double* Lf = var + (size_t)n * pp;
@@ -651,12 +738,17 @@ __global__ void __launch_bounds__(DT) dense_sqrt_bwd_mv_kernel(DenseArgs a) {
         for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = mu_s[i] - w.mup[i];
         __syncthreads();
         // L_s = add_sqrt(G [L_next | R^{1/2}], J L_f): rows of the stacked matrix = (G L_next)^T, (G R^{1/2})^T, (J L_f)^T
+        RK_STAMP_RESET();
         wg_gemm(gemm_op(w.S, p, Ls, p, true, w.A3, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
         wg_gemm(gemm_op(w.S + pp, p, a.R, p, true, w.A3, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
         wg_gemm(gemm_op(w.S + 2 * pp, p, Lf, p, true, w.A1, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
+        RK_STAMP(5);
         dense_sqrt_mean(w, mu_f, mu_f, p);                                                    // square_root.py:211-212
-        wg_qr_r(w.S, p, 3 * p, p);
+        RK_STAMP(6);
+        wg_qr_r(w.S, p, 3 * p, p, ws_end);
+        RK_STAMP(7);
         wg_transpose(Lf, p, w.S, p, p, p, 1);
+        RK_STAMP(8);
     }
 }
 

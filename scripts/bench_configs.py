@@ -89,7 +89,21 @@ def c5(args):
     p, m = 160, 32
     F = (12 + 2 / 3) * p ** 3 + 4 * m * p * p + 4 * m * m * p + (2 / 3) * m ** 3
     ms = sum(prof.values())
-    if os.environ.get("RK_DENSE_STAMPS") == "fwd":
+    if os.environ.get("RK_DENSE_STAMPS") and args.c5_kalman == "square-root":
+        # library built with `make -C rodeo_amd/csrc stamps`, loaded through RK_LIB_PATH (solve_dense_sqrt.hpp)
+        nb = ["S gemms", "L^-1 Q", "X Sigma_f", "L^-T .", "J^T", "stack gemms", "mean", "QR 3p x p", "store"]
+        nq = ["QR panel", "QR T + W pass", "QR T^T W", "QR rank-16 update"]
+        nf = ["(QL)^T, R^T", "QR 2p x p", "stores + mu-", "interrogation", "W~L, stack", "QR (p+kv) x m", "tri solves m", "K gemms",
+              "D, stack", "QR (p+kv) x p"]
+        sq_stride = (6 * p * p + 4 * m * p + (p + m) * m + m * m) + 2 * p + 2 * m + 16
+        bw = plan._ws.to_host()[:sq_stride][::-1][1:16]              # stamps_[-2 - k] of trajectory 0 after the backward pass
+        print("sqrt bwd phase cycles per step (wg 0):", {k: int(v / (N - 1)) for k, v in zip(nb, bw[:9])},
+              {k: int(v / (N - 1)) for k, v in zip(nq, bw[10:14])}, file=sys.stderr)
+        plan.filter(None); dev.sync()
+        fw = plan._ws.to_host()[:sq_stride][::-1][1:16]
+        print("sqrt fwd phase cycles per step (wg 0):", {k: int(v / N) for k, v in zip(nf, fw[:10])},
+              {k: int(v / N) for k, v in zip(nq, fw[10:14])}, file=sys.stderr)
+    elif os.environ.get("RK_DENSE_STAMPS") == "fwd":
         plan.filter(None); dev.sync()
         ws = plan._ws.to_host().reshape(B, -1)
         names = ["Q Sigma", "(Q Sigma) Q^T + R", "mu-", "interrogation + W~ Sigma-", "S", "Sigma- W~^T", "LU + mean + downdate"]
