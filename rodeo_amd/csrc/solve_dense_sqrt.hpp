@@ -28,8 +28,8 @@
 
 namespace rk {
 
-constexpr int QR_RT = 15;                               // panel rows below the triangle per lane: panels of up to 496 rows
-constexpr int QR_MAXM = 16 + 32 * QR_RT;
+constexpr int QR_RT = 30;                               // panel rows below the triangle per lane: panels of up to 496 rows
+constexpr int QR_MAXM = 16 + 16 * QR_RT;
 
 __device__ __forceinline__ double readlane_f64(double x, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
@@ -97,90 +97,104 @@ __device__ __forceinline__ double slab_sum(double x) {                // x(l) + 
     return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
+// The panel is factored by the FIRST FOUR waves, one per SIMD (the column steps are VALU-issue-bound: with two waves on a
+// SIMD each step took the sum of both instruction streams -- 8 waves x 15 rows per lane ran 1.6x slower than 4 x 30); the
+// other four only take part in the barriers.
+constexpr int QR_PW = 4;                                // panel waves
 template <int RT, int J>
-__device__ __forceinline__ void qr_panel_col(double (&tr)[16], double (&ta)[RT], double& myscale, int c, int wave, int lane,
-                                             int pg_off, int tau_off) {
+__device__ __forceinline__ void qr_panel_col(double (&tr)[16], double (&ta)[RT], double& myscale, bool act, int c, int wave,
+                                             int lane, int pg_off, int tau_off) {
     double pt[16], pu[RT];
+    double gt = 0.0;
+    double* const bb = g_lds + pg_off + (J & 1) * (16 * QR_PW);      // [c][wave]: partial dots of the rows below the triangle
+    if (act) {
 #pragma unroll
-    for (int i = J; i < 16; ++i) pt[i] = readlane_f64(tr[i], J);
+        for (int i = J; i < 16; ++i) pt[i] = readlane_f64(tr[i], J);
 #pragma unroll
-    for (int i = 0; i < RT; ++i) pu[i] = row_bcast_f64<J>(ta[i]);
-    double gt = 0.0, nt = 0.0, gu = 0.0, nu = 0.0;
+        for (int i = 0; i < RT; ++i) pu[i] = row_bcast_f64<J>(ta[i]);
+        double gu = 0.0;
 #pragma unroll
-    for (int i = J + 1; i < 16; ++i) { gt = fma(pt[i], tr[i], gt); nt = fma(pt[i], pt[i], nt); }
+        for (int i = J + 1; i < 16; ++i) gt = fma(pt[i], tr[i], gt);
 #pragma unroll
-    for (int i = 0; i < RT; ++i) { gu = fma(pu[i], ta[i], gu); nu = fma(pu[i], pu[i], nu); }
-    gu = slab_sum(gu);
-    nu = slab_sum(nu);
-    double* const bb = g_lds + pg_off + (J & 1) * 136;  // [c][wave] partial dots, then [wave] partial norms
-    if (lane < 16) bb[c * 8 + wave] = gu;
-    if (lane == 0) bb[128 + wave] = nu;
+        for (int i = 0; i < RT; ++i) gu = fma(pu[i], ta[i], gu);
+        gu = slab_sum(gu);
+        if (lane < 16) bb[c * QR_PW + wave] = gu;
+    }
     __syncthreads();
-    double G = 0.0, Nn = 0.0;
+    if (act) {
+        double G = 0.0, Nn = 0.0;
 #pragma unroll
-    for (int w = 0; w < NWAVE; ++w) { G += bb[c * 8 + w]; Nn += bb[128 + w]; }
-    // LAPACK dlarfg: beta = -sign(alpha) ||(alpha, x)||, tau = (beta - alpha) / beta, v = x / (alpha - beta), v_J = 1
-    const double alpha = pt[J], xn2 = nt + Nn;
-    const bool refl = xn2 != 0.0;
-    const double beta = refl ? -copysign(sqrt(fma(alpha, alpha, xn2)), alpha) : alpha;
-    const double tau = refl ? (beta - alpha) * fast_rcp(beta) : 0.0;
-    const double scale = refl ? fast_rcp(alpha - beta) : 0.0;
-    if (threadIdx.x == 0) g_lds[tau_off + J] = tau;
-    // w_c = tau (a_Jc + v_below . a_c) for the columns right of J;  a_c <- a_c - v w_c with v = x scale
-    const bool right = c > J, piv = c == J;
-    const double wc = right ? tau * fma(scale, gt + G, tr[J]) : 0.0;
-    myscale = piv ? scale : myscale;
-    tr[J] = piv ? beta : tr[J] - wc;
-    const double z = -(scale * wc);
+        for (int w = 0; w < QR_PW; ++w) { G += bb[c * QR_PW + w]; Nn += bb[J * QR_PW + w]; }
+        // LAPACK dlarfg: beta = -sign(alpha) ||(alpha, x)||, tau = (beta - alpha) / beta, v = x / (alpha - beta), v_J = 1
+        // (||x||^2 = the pivot column's dot product with itself: lane J's triangle part, column J's exchanged sums)
+        const double alpha = pt[J], xn2 = readlane_f64(gt, J) + Nn;
+        const bool refl = xn2 != 0.0;
+        const double beta = refl ? -copysign(sqrt(fma(alpha, alpha, xn2)), alpha) : alpha;
+        const double tau = refl ? (beta - alpha) * fast_rcp(beta) : 0.0;
+        const double scale = refl ? fast_rcp(alpha - beta) : 0.0;
+        if (threadIdx.x == 0) g_lds[tau_off + J] = tau;
+        // w_c = tau (a_Jc + v_below . a_c) for the columns right of J;  a_c <- a_c - v w_c with v = x scale
+        const bool right = c > J, piv = c == J;
+        const double wc = right ? tau * fma(scale, gt + G, tr[J]) : 0.0;
+        myscale = piv ? scale : myscale;
+        tr[J] = piv ? beta : tr[J] - wc;
+        const double z = -(scale * wc);
 #pragma unroll
-    for (int i = J + 1; i < 16; ++i) tr[i] = fma(pt[i], z, tr[i]);
+        for (int i = J + 1; i < 16; ++i) tr[i] = fma(pt[i], z, tr[i]);
 #pragma unroll
-    for (int i = 0; i < RT; ++i) ta[i] = fma(pu[i], z, ta[i]);
+        for (int i = 0; i < RT; ++i) ta[i] = fma(pu[i], z, ta[i]);
+    }
 }
 template <int RT, int J>
-__device__ __forceinline__ void qr_panel_cols(double (&tr)[16], double (&ta)[RT], double& myscale, int c, int wave, int lane,
-                                              int nb, int pg_off, int tau_off) {
+__device__ __forceinline__ void qr_panel_cols(double (&tr)[16], double (&ta)[RT], double& myscale, bool act, int c, int wave,
+                                              int lane, int nb, int pg_off, int tau_off) {
     if constexpr (J < 16) {
-        if (J < nb) qr_panel_col<RT, J>(tr, ta, myscale, c, wave, lane, pg_off, tau_off);
+        if (J < nb) qr_panel_col<RT, J>(tr, ta, myscale, act, c, wave, lane, pg_off, tau_off);
         else if (threadIdx.x == 0) g_lds[tau_off + J] = 0.0;
-        qr_panel_cols<RT, J + 1>(tr, ta, myscale, c, wave, lane, nb, pg_off, tau_off);
+        qr_panel_cols<RT, J + 1>(tr, ta, myscale, act, c, wave, lane, nb, pg_off, tau_off);
     }
 }
 
-// Factors the panel P (Mk <= 16 + 32 RT rows, nb <= 16 columns, row stride ld, in global memory): R11's upper triangle back
-// to P, V (unit lower trapezoid, explicit ones and zeros) to the LDS panel g_lds[r * LU_LD + c], tau to g_lds[tau_off ..].
+// Factors the panel P (Mk <= 16 + 16 RT rows, nb <= 16 columns, row stride ld, in global memory): R11's upper triangle back
+// to P, V (unit lower trapezoid, explicit ones and zeros; zero rows up to the next multiple of 16) to the LDS panel
+// g_lds[r * LU_LD + c], tau to g_lds[tau_off ..].  Thread t < 256: column c = t & 15 of slab s = t >> 4 (16 slabs).
 template <int RT>
 __device__ __forceinline__ void qr_panel_body(double* P_, int ld_, int Mk_, int nb_, int pg_off_, int tau_off_) {
     auto* const P = uni_g(P_);
     const int ld = uni(ld_), Mk = uni(Mk_), nb = uni(nb_), pg_off = uni(pg_off_), tau_off = uni(tau_off_);
     const int tid = threadIdx.x, c = tid & 15, s = tid >> 4, lane = tid & 63, wave = uni((int)(tid >> 6));
+    const bool act = wave < QR_PW;
     double tr[16], ta[RT], myscale = 0.0;
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tr[i] = (c < nb && i < Mk) ? P[(size_t)i * ld + c] : 0.0;
+        for (int i = 0; i < 16; ++i) tr[i] = (c < nb && i < Mk) ? P[(size_t)i * ld + c] : 0.0;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int r = 16 + s + 32 * i;
-        ta[i] = (c < nb && r < Mk) ? P[(size_t)r * ld + c] : 0.0;
-    }
-    qr_panel_cols<RT, 0>(tr, ta, myscale, c, wave, lane, nb, pg_off, tau_off);
-    double* const panel = g_lds;
-    if (s == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < Mk) panel[i * LU_LD + c] = i > c ? tr[i] * myscale : ((i == c && c < nb) ? 1.0 : 0.0);
-            if (i <= c && c < nb && i < Mk) P[(size_t)i * ld + c] = tr[i];
+        for (int i = 0; i < RT; ++i) {
+            const int r = 16 + s + 16 * i;
+            ta[i] = (c < nb && r < Mk) ? P[(size_t)r * ld + c] : 0.0;
         }
     }
+    qr_panel_cols<RT, 0>(tr, ta, myscale, act, c, wave, lane, nb, pg_off, tau_off);
+    double* const panel = g_lds;
+    if (act) {
+        if (s == 0) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int r = 16 + s + 32 * i;
-        if (r < Mk) panel[r * LU_LD + c] = ta[i] * myscale;
+            for (int i = 0; i < 16; ++i) {
+                if (i < Mk) panel[i * LU_LD + c] = i > c ? tr[i] * myscale : ((i == c && c < nb) ? 1.0 : 0.0);
+                if (i <= c && c < nb && i < Mk) P[(size_t)i * ld + c] = tr[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int r = 16 + s + 16 * i;
+            if (r < Mk) panel[r * LU_LD + c] = ta[i] * myscale;
+        }
     }
     for (int e = tid; e < (((Mk + 15) & ~15) - Mk) * 16; e += DT) panel[(Mk + (e >> 4)) * LU_LD + (e & 15)] = 0.0;   // whole tiles
     __syncthreads();
 }
-__device__ __noinline__ void qr_panel7(double* P, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<7>(P, ld, Mk, nb, pg_off, tau_off); }
-__device__ __noinline__ void qr_panel15(double* P, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<QR_RT>(P, ld, Mk, nb, pg_off, tau_off); }
+__device__ __noinline__ void qr_panel14(double* P, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<14>(P, ld, Mk, nb, pg_off, tau_off); }
+__device__ __noinline__ void qr_panel30(double* P, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<QR_RT>(P, ld, Mk, nb, pg_off, tau_off); }
 
 // T (16 x 16 upper triangular, g_lds[t_off + i * 16 + j]) of the compact WY form from the LDS panel V and tau:
 // T_jj = tau_j, T(0:j, j) = -tau_j T(0:j, 0:j) (V^T V)(0:j, j)   (LAPACK dlarft, forward / columnwise).
@@ -356,13 +370,13 @@ __device__ __noinline__ void wg_qr_r(double* S_, int ld_, int M_, int n_, double
     const int ld = uni(ld_), M = uni(M_), n = uni(n_);
     RK_STAMP_DECL(ws_end);
     const int gp_off = (((M + 15) & ~15) * LU_LD + 1) & ~1, t_off = gp_off + NWAVE * 256, tau_off = t_off + 256, pg_off = tau_off + 16;
-    const int px_off = pg_off + 2 * 136;                // partial W tiles of the fused update: 2 x 8 x 256
+    const int px_off = pg_off + 2 * 16 * QR_PW;                // partial W tiles of the fused update: 2 x 8 x 256
     if (M > QR_MAXM || px_off + 2 * NWAVE * 256 > LDS_DOUBLES) { wg_qr_r_unblocked((double*)S, ld, M, n); return; }
     __syncthreads();
     for (int k0 = 0; k0 < n && k0 < M; k0 += 16) {
         const int nb = min(16, n - k0), Mk = M - k0, n2 = n - k0 - nb;
-        if (Mk <= 16 + 32 * 7) qr_panel7((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
-        else qr_panel15((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
+        if (Mk <= 16 + 16 * 14) qr_panel14((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
+        else qr_panel30((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
         RK_STAMP(10);
         if (n2 > 0) {
             qr_build_T(Mk, gp_off, t_off, tau_off);
