@@ -433,8 +433,8 @@ __device__ __forceinline__ void lu_panel_cols(double (&a)[RS][LU_NB], int (&pos)
     }
 }
 template <int RS>
-__device__ __forceinline__ void lu_panel_regs(int rows, int nb) {
-    double* const panel = g_lds;
+__device__ __forceinline__ void lu_panel_regs(int rows, int nb, int poff) {
+    double* const panel = g_lds + poff;
     const int l = threadIdx.x;                             // lane of wave 0
     double a[RS][LU_NB];
     int pos[RS];
@@ -456,22 +456,35 @@ __device__ __forceinline__ void lu_panel_regs(int rows, int nb) {
     }
 }
 
-__device__ __noinline__ void lu_panel_wave3(int rows_, int nb_) { lu_panel_regs<3>(uni(rows_), uni(nb_)); }   // rows <= 192
-__device__ __noinline__ void lu_panel_wave5(int rows_, int nb_) { lu_panel_regs<5>(uni(rows_), uni(nb_)); }   // rows <= 320
+__device__ __noinline__ void lu_panel_wave1(int rows_, int nb_, int poff_ = 0) { lu_panel_regs<1>(uni(rows_), uni(nb_), uni(poff_)); }   // rows <= 64
+__device__ __noinline__ void lu_panel_wave2(int rows_, int nb_, int poff_ = 0) { lu_panel_regs<2>(uni(rows_), uni(nb_), uni(poff_)); }   // rows <= 128
+__device__ __noinline__ void lu_panel_wave3(int rows_, int nb_, int poff_ = 0) { lu_panel_regs<3>(uni(rows_), uni(nb_), uni(poff_)); }   // rows <= 192
+__device__ __noinline__ void lu_panel_wave5(int rows_, int nb_, int poff_ = 0) { lu_panel_regs<5>(uni(rows_), uni(nb_), uni(poff_)); }   // rows <= 320
+// wave 0: the panel in the LDS buffer at poff, with as few register rows per lane as its row count needs (the column steps
+// are a dependent chain on this one wave -- the critical path of the whole solve)
+__device__ __forceinline__ void lu_panel_wave(int rows, int nb, int poff) {
+    if (rows <= 64) lu_panel_wave1(rows, nb, poff);
+    else if (rows <= 128) lu_panel_wave2(rows, nb, poff);
+    else if (rows <= 192) lu_panel_wave3(rows, nb, poff);
+    else lu_panel_wave5(rows, nb, poff);
+}
 
 // rank-16 update  C <- C - L U  for the tiles (rb, ct): rows r0 + 16 rb.., a strip of column tiles; L rows from the LDS
 // panel `lp` (row stride LU_LD, row index rb * 16 + i, columns < nb), U from the LDS strip `us` (row stride usp).
 // Column tiles ct < ctA address C1 (ld1, n1 valid columns), the others C2 (ld2, n2 valid columns) at strip offset offB.
 __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int us_off, int usp_, int rt_,
                                             double* C1_, int ld1_, int n1_, int ctA_, double* C2_, int ld2_, int n2_, int ctB_,
-                                            int offB_, int mrows_) {
+                                            int offB_, int mrows_, int wave0_ = 0, int nwaves_ = NWAVE) {
     const double* const lp = g_lds + uni(lp_off);
     const double* const us = g_lds + uni(us_off);
     const int lrows = uni(lrows_), nb = uni(nb_), usp = uni(usp_), rt = uni(rt_), ld1 = uni(ld1_), n1 = uni(n1_), ctA = uni(ctA_);
     const int ld2 = uni(ld2_), n2 = uni(n2_), ctB = uni(ctB_), offB = uni(offB_), mrows = uni(mrows_);
     auto* const C1 = uni_g(C1_);
     auto* const C2 = uni_g(C2_);
-    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
+    // the tiles are dealt to the waves wave0 .. wave0 + nwaves - 1 (look-ahead: wave 0 factors the next panel meanwhile)
+    const int wave0 = uni(wave0_), nwaves = uni(nwaves_);
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)) - wave0, lo = lane & 15, hi = lane >> 4;
+    if (wave < 0 || wave >= nwaves) return;
     const int nct = ctA + ctB, tiles = rt * nct;
     // Tiles wave, wave + 8, ... in groups of RU_G: the C values of the NEXT group are loaded before the current group is
     // multiplied and stored (a tile is 4 loads, 4 MFMAs, 4 stores; without this every tile waits a full memory round trip).
@@ -489,7 +502,7 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
     auto load_group = [&](int e0, d4 (&c)[RU_G]) {
 #pragma unroll
         for (int u = 0; u < RU_G; ++u) {
-            const int e = e0 + u * NWAVE;
+            const int e = e0 + u * nwaves;
             if (e < tiles) {
                 gd* Cm; int ld, cj, sj, rb; bool cok;
                 tile_of(e, Cm, ld, cj, sj, rb, cok);
@@ -503,11 +516,11 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
     };
     d4 cur[RU_G], nxt[RU_G];
     load_group(wave, cur);
-    for (int e0 = wave; e0 < tiles; e0 += RU_G * NWAVE) {
-        load_group(e0 + RU_G * NWAVE, nxt);
+    for (int e0 = wave; e0 < tiles; e0 += RU_G * nwaves) {
+        load_group(e0 + RU_G * nwaves, nxt);
 #pragma unroll
         for (int u = 0; u < RU_G; ++u) {
-            const int e = e0 + u * NWAVE;
+            const int e = e0 + u * nwaves;
             if (e < tiles) {
                 gd* Cm; int ld, cj, sj, rb; bool cok;
                 tile_of(e, Cm, ld, cj, sj, rb, cok);
@@ -529,6 +542,47 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
         }
 #pragma unroll
         for (int u = 0; u < RU_G; ++u) cur[u] = nxt[u];
+    }
+}
+
+// x <- E11^{-1} x for ONE right-hand-side column and a 16 x 16 triangular block E11 whose row j lies in LDS at
+// prow0[j * LU_LD + 0 .. 15] (every thread reads the same addresses: broadcasts).  LOWER: forward substitution from row 0,
+// else back substitution from row 15; UNIT: unit diagonal (the L of the LU), else x_j is scaled by rdiag[j] = 1 / e_jj.
+// Entries of x from nb on are zero on entry and on exit; columns >= nb of the staged block are zero or meet those zeros.
+// The substitution is a dependent chain, so what matters is what sits ON the chain: each row's block entries are read one
+// row AHEAD (tied by an empty asm to the result two rows back, so that hipcc neither issues all 120 reads up front -- they
+// spill -- nor waits for every single read, which is what a branch per entry made of the first version: 750 cycles per
+// row), and a row's sum runs in two independent accumulators.
+template <bool LOWER, bool UNIT>
+__device__ __forceinline__ void trsm16(double (&x)[LU_NB], const double* prow0, int nb, const double* rdiag) {
+    double rowv[2][LU_NB];
+    auto row_of = [](int step) { return LOWER ? step : LU_NB - 1 - step; };
+    auto load_row = [&](int step, int off) {
+        const int j = row_of(step);
+        const double* const pr = prow0 + j * LU_LD + off;
+#pragma unroll
+        for (int i = 0; i < LU_NB; ++i)
+            if (LOWER ? i < j : i > j) rowv[step & 1][i] = pr[i];
+    };
+    load_row(0, 0);
+    load_row(1, 0);
+#pragma unroll
+    for (int step = 0; step < LU_NB; ++step) {
+        const int j = row_of(step);
+        double s0 = x[j], s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < LU_NB; ++i)
+            if (LOWER ? i < j : i > j) {
+                if (i & 1) s1 = fma(-rowv[step & 1][i], x[i], s1);
+                else s0 = fma(-rowv[step & 1][i], x[i], s0);
+            }
+        const double sacc = s0 + s1;
+        x[j] = j < nb ? (UNIT ? sacc : sacc * rdiag[j]) : 0.0;
+        if (step + 2 < LU_NB) {
+            int off = 0;
+            asm("" : "+v"(off) : "v"(x[j]));                         // row step + 2 is read once row step is done
+            load_row(step + 2, off);
+        }
     }
 }
 
@@ -554,25 +608,15 @@ __device__ __forceinline__ void lu_swap_cols(gd* M, int ld, int ncols, int nm) {
 // X = L11^{-1} M for the 16-row block M (row stride ld, `ncols` columns; unit lower triangle from the LDS panel), one
 // thread per column; results to memory and to the LDS strip at column offset `soff` (zero in the padding columns up
 // to `npad` and in rows >= nb)
-__device__ __forceinline__ void lu_trsm_lower(gd* M, int ld, int ncols, int npad, int nb, double* us, int usp, int soff) {
-    const double* const panel = g_lds;
+__device__ __forceinline__ void lu_trsm_lower(gd* M, int ld, int ncols, int npad, int nb, double* us, int usp, int soff, int poff = 0) {
+    const double* const panel = g_lds + poff;
     for (int c = threadIdx.x; c < npad; c += DT) {
         asm volatile("" ::: "memory");
         const bool ok = c < ncols;
         double x[LU_NB];
 #pragma unroll
         for (int j = 0; j < LU_NB; ++j) x[j] = (ok && j < nb) ? (M + j * ld)[c] : 0.0;
-#pragma unroll
-        for (int j = 1; j < LU_NB; ++j) {
-            int pj = j * LU_LD;
-            asm("" : "+v"(pj) : "v"(x[j - 1]));          // row j's panel reads wait for x[j-1]: hipcc otherwise issues all
-                                                         // 120 reads up front and spills them
-            double sacc = x[j];
-#pragma unroll
-            for (int i = 0; i < j; ++i)
-                if (j < nb) sacc = fma(-panel[pj + i], x[i], sacc);
-            x[j] = j < nb ? sacc : 0.0;
-        }
+        trsm16<true, true>(x, panel, nb, nullptr);
 #pragma unroll
         for (int j = 0; j < LU_NB; ++j) {
             if (ok && j < nb) (M + j * ld)[c] = x[j];
@@ -590,16 +634,7 @@ __device__ __forceinline__ void lu_trsm_upper(gd* M, int ld, int k0, int nb, int
         double x[LU_NB];
 #pragma unroll
         for (int j = 0; j < LU_NB; ++j) x[j] = (c < nr && j < nb) ? (M + j * ld)[c] : 0.0;
-#pragma unroll
-        for (int j = LU_NB - 1; j >= 0; --j) {
-            int pj = (k0 + j) * LU_LD;
-            if (j < LU_NB - 1) asm("" : "+v"(pj) : "v"(x[j + 1]));
-            double sacc = x[j];
-#pragma unroll
-            for (int i = j + 1; i < LU_NB; ++i)
-                if (i < nb) sacc = fma(-panel[pj + i], x[i], sacc);
-            x[j] = j < nb ? sacc * g_rdiag[j] : 0.0;
-        }
+        trsm16<false, false>(x, panel + k0 * LU_LD, nb, g_rdiag);
 #pragma unroll
         for (int j = 0; j < LU_NB; ++j) {
             if (c < nr && j < nb) (M + j * ld)[c] = x[j];
@@ -616,100 +651,12 @@ __device__ __forceinline__ void lu_trsm_upper(gd* M, int ld, int k0, int nb, int
 // owners take the solved tiles back and every wave updates its tiles above with rank-16 MFMAs (A fragments from the
 // staged block column, B fragments from the scratches).  Same operations in the same order as the block-row loop.
 constexpr int BS_T = 10, BS_Q = (BS_T * BS_T + NWAVE - 1) / NWAVE;
-constexpr int BS_SCR = BS_T * 16 * LU_LD;                 // doubles: panel region, then the ten scratches
 
-// threads 0 .. 16 nct - 1: X = U11^{-1} Y for column (tid & 15) of the tile in scratch (tid >> 4)
-__device__ __noinline__ void backsub_trsm_all(int k0_, int nb_, int nct_) {
-    const int k0 = uni(k0_), nb = uni(nb_), nct = uni(nct_);
-    if ((int)threadIdx.x >= 16 * nct) return;
-    const double* const panel = g_lds;
-    double* const scratch = g_lds + BS_SCR + (threadIdx.x >> 4) * 16 * LU_LD;
-    const int lo = threadIdx.x & 15;
-    double x[LU_NB];
-#pragma unroll
-    for (int j = 0; j < LU_NB; ++j) x[j] = j < nb ? scratch[j * LU_LD + lo] : 0.0;
-#pragma unroll
-    for (int j = LU_NB - 1; j >= 0; --j) {
-        int pj = (k0 + j) * LU_LD;
-        if (j < LU_NB - 1) asm("" : "+v"(pj) : "v"(x[j + 1]));          // (see lu_trsm_upper)
-        double sacc = x[j];
-#pragma unroll
-        for (int i = j + 1; i < LU_NB; ++i)
-            if (i < nb) sacc = fma(-panel[pj + i], x[i], sacc);
-        x[j] = j < nb ? sacc * g_rdiag[j] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < LU_NB; ++j) scratch[j * LU_LD + lo] = x[j];
-}
-
-__device__ __noinline__ void lu_backsub_regs(const double* A_, int lda_, double* Bm_, int ldb_, int n_, int nr_) {
-    auto* const A = uni_g(A_);
-    auto* const Bm = uni_g(Bm_);
-    const int lda = uni(lda_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
-    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
-    const int nbk = (n + 15) >> 4, nct = (nr + 15) >> 4;
-    double* const panel = g_lds;
-    double* const scr = g_lds + BS_SCR;
-    d4 t[BS_Q];
-#pragma unroll
-    for (int q = 0; q < BS_Q; ++q) {
-        const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int row = 16 * rb + 4 * v + hi, col = 16 * ct + lo;
-            double y = Bm[min(row, n - 1) * ldb + min(col, nr - 1)];            // clamped and unconditional: the loads stay batched
-            asm("" : "+v"(y));                                                  // (hipcc otherwise sinks each load into its own branch)
-            t[q][v] = (row < n && col < nr) ? y : 0.0;
-        }
-    }
-    for (int k = nbk - 1; k >= 0; --k) {
-        const int k0 = 16 * k, nb = min(16, n - k0);
-        __syncthreads();                                            // the previous block's panel and scratches are free
-        for (int e = threadIdx.x; e < (k0 + nb) * LU_NB; e += DT) {
-            const int r = e >> 4, c = e & 15;
-            panel[r * LU_LD + c] = c < nb ? A[r * lda + k0 + c] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < BS_Q; ++q) {
-            const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
-            if (rb == k && ct < nct) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) scr[ct * 16 * LU_LD + (4 * v + hi) * LU_LD + lo] = t[q][v];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < nb) g_rdiag[threadIdx.x] = 1.0 / panel[(k0 + threadIdx.x) * LU_LD + threadIdx.x];
-        __syncthreads();
-        backsub_trsm_all(k0, nb, nct);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < BS_Q; ++q) {
-            const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
-            if (ct < nct && rb <= k) {
-                const double* const sc = scr + ct * 16 * LU_LD;
-                if (rb == k) {                                      // the solved tile: X_k
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) t[q][v] = sc[(4 * v + hi) * LU_LD + lo];
-                } else {                                            // Y_rb -= U(rb, k) X_k
-#pragma unroll
-                    for (int kq = 0; kq < 4; ++kq)
-                        t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-panel[(16 * rb + lo) * LU_LD + 4 * kq + hi],
-                                                                    sc[(4 * kq + hi) * LU_LD + lo], t[q], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < BS_Q; ++q) {
-        const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int row = 16 * rb + 4 * v + hi, col = 16 * ct + lo;
-            if (e < BS_T * BS_T && row < n && col < nr) Bm[row * ldb + col] = t[q][v];
-        }
-    }
-    __syncthreads();
-}
+// X = E^{-1} B with the right-hand side resident in registers, E triangular (solve_dense_sqrt.hpp: the back substitution of
+// the LU below is its upper / non-transposed case)
+template <bool LOWER>
+__device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int trans_, double* Bm_, int ldb_, int n_, int nr_,
+                                               double* ws_end_ = nullptr);
 
 __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int ldb_, int n_, int nr_, int* piv_,
                                          double* ws_end_ = nullptr) {
@@ -724,21 +671,31 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
     const int nrp = (n + 15) & ~15, nbp = (nr + 15) & ~15;      // strip: [0, nrt) trailing columns, [nrt, nrt + nbp) right-hand sides
     const int usp = (nrp + nbp + 16) | 1;                       // odd row stride
     if (n > LU_MAXN || n * LU_LD + LU_NB * usp > LDS_DOUBLES) { wg_lu_solve_unblocked(lds, (double*)A, lda, (double*)Bm, ldb, n, nr, (int*)piv); return; }
-    double* const panel = lds;
-    const int us_off = n * LU_LD;
     const int tid = threadIdx.x;
+    // Look-ahead (when two panel buffers fit): after the swaps and the L11 solves of panel k, the rank-16 update is applied
+    // FIRST to the 16 columns of the next panel by all waves; then wave 0 copies and factors panel k + 1 (wave-synchronous,
+    // no workgroup barrier inside) while waves 1-7 apply the update to the other columns and to the right-hand sides.
+    const bool la = 2 * n * LU_LD + LU_NB * usp <= LDS_DOUBLES;
+    const int us_off = (la ? 2 : 1) * n * LU_LD;
+    auto copy_panel = [&](int k0, int poff, int t0, int nt) {              // rows k0.., columns k0 .. k0 + nb - 1 -> LDS
+        const int nb = min(LU_NB, n - k0), rows = n - k0;
+        double* const pn = lds + poff;
+        for (int e = t0; e < rows * LU_NB; e += nt) {
+            const int r = e >> 4, c = e & 15;
+            pn[r * LU_LD + c] = c < nb ? A[(k0 + r) * lda + k0 + c] : 0.0;
+        }
+        for (int r = t0; r < rows; r += nt) g_cur[r] = r;
+        if (t0 == 0) g_mcount = 0;
+    };
+    copy_panel(0, 0, tid, DT);
+    __syncthreads();
+    if (tid < 64) lu_panel_wave(n, min(LU_NB, n), 0);
+    __syncthreads();
+    RK_STAMP(1);
     for (int k0 = 0; k0 < n; k0 += LU_NB) {
         const int nb = min(LU_NB, n - k0), rows = n - k0, n_right = n - k0 - nb;
-        for (int e = tid; e < rows * LU_NB; e += DT) {
-            const int r = e >> 4, c = e & 15;
-            if (c < nb) panel[r * LU_LD + c] = A[(k0 + r) * lda + k0 + c];
-        }
-        for (int r = tid; r < rows; r += DT) g_cur[r] = r;
-        if (tid == 0) g_mcount = 0;
-        __syncthreads();
-        if (tid < 64) { if (rows <= 192) lu_panel_wave3(rows, nb); else lu_panel_wave5(rows, nb); }
-        __syncthreads();
-        RK_STAMP(1);
+        const int poff = la ? ((k0 / LU_NB) & 1) * n * LU_LD : 0;
+        double* const panel = lds + poff;
         // the diagonal block back to A (its upper triangle is U11, needed by the back substitution); pivots
         if (tid < nb * LU_NB) {
             const int r = tid >> 4, c = tid & 15;
@@ -758,29 +715,53 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         __syncthreads();
         RK_STAMP(2);
         const int nrt = (n_right + 15) & ~15;                         // trailing columns padded to whole tiles
-        lu_trsm_lower(A + (size_t)k0 * lda + k0 + nb, lda, n_right, nrt, nb, lds + us_off, usp, 0);
-        lu_trsm_lower(Bm + (size_t)k0 * ldb, ldb, nr, nbp, nb, lds + us_off, usp, nrt);
+        lu_trsm_lower(A + (size_t)k0 * lda + k0 + nb, lda, n_right, nrt, nb, lds + us_off, usp, 0, poff);
+        lu_trsm_lower(Bm + (size_t)k0 * ldb, ldb, nr, nbp, nb, lds + us_off, usp, nrt, poff);
         __syncthreads();
         RK_STAMP(3);
-        if (n_right > 0)
-            lu_rank_update(nb * LU_LD, n_right, nb, us_off, usp, (n_right + 15) >> 4,
+        const int rt = (n_right + 15) >> 4;
+        if (n_right > 0 && la) {
+            // the next panel's columns first ...
+            lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off, usp, rt, (double*)(A + (size_t)(k0 + nb) * lda + k0 + nb), lda,
+                           min(LU_NB, n_right), 1, (double*)(Bm + (size_t)(k0 + nb) * ldb), ldb, 0, 0, nrt, n_right);
+            __syncthreads();
+            // ... then wave 0 factors them while the others update the rest
+            if (tid < 64) {
+                const int k1 = k0 + nb, p1 = (((k1 / LU_NB) & 1)) * n * LU_LD;
+                copy_panel(k1, p1, tid, 64);
+                wave_lds_sync();
+                lu_panel_wave(n - k1, min(LU_NB, n - k1), p1);
+            } else {
+                // column tiles 1 .. of the trailing matrix (strip offset 16), then the right-hand sides
+                lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off + LU_NB, usp, rt,
+                               (double*)(A + (size_t)(k0 + nb) * lda + k0 + nb + LU_NB), lda, max(n_right - LU_NB, 0), (nrt >> 4) - 1,
+                               (double*)(Bm + (size_t)(k0 + nb) * ldb), ldb, nr, nbp >> 4, nrt - LU_NB, n_right, 1, NWAVE - 1);
+            }
+        } else if (n_right > 0) {
+            lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off, usp, rt,
                            (double*)(A + (size_t)(k0 + nb) * lda + k0 + nb), lda, n_right, nrt >> 4,
                            (double*)(Bm + (size_t)(k0 + nb) * ldb), ldb, nr, nbp >> 4, nrt, n_right);
+            __syncthreads();
+            copy_panel(k0 + nb, 0, tid, DT);
+            __syncthreads();
+            if (tid < 64) lu_panel_wave(n_right, min(LU_NB, n_right), 0);
+        }
         __syncthreads();
         RK_STAMP(4);
     }
     if (n > 64 && n <= 16 * BS_T && nr <= 16 * BS_T && DT == 512) {     // right-hand side resident in registers
-        lu_backsub_regs((const double*)A, lda, (double*)Bm, ldb, n, nr);
+        wg_tri_solve_regs<false>((const double*)A, lda, 0, (double*)Bm, ldb, n, nr);
         RK_STAMP(5);
         return;
     }
     // back substitution with U, block rows from the bottom
+    double* const panel = lds;
     for (int k0 = ((n - 1) / LU_NB) * LU_NB; k0 >= 0; k0 -= LU_NB) {
         const int nb = min(LU_NB, n - k0);
         // block column k0 of U, rows 0 .. k0 + nb - 1, into the panel buffer (U11 = its last nb rows)
         for (int e = tid; e < (k0 + nb) * LU_NB; e += DT) {
             const int r = e >> 4, c = e & 15;
-            if (c < nb) panel[r * LU_LD + c] = A[r * lda + k0 + c];
+            panel[r * LU_LD + c] = c < nb ? A[r * lda + k0 + c] : 0.0;
         }
         __syncthreads();
         if (tid < nb) g_rdiag[tid] = 1.0 / panel[(k0 + tid) * LU_LD + tid];

@@ -28,6 +28,9 @@
 
 namespace rk {
 
+#ifndef RK_STAMP_TRI
+#define RK_STAMP_TRI 0
+#endif
 constexpr int QR_RT = 30;                               // panel rows below the triangle per lane: panels of up to 496 rows
 constexpr int QR_MAXM = 16 + 16 * QR_RT;
 
@@ -394,51 +397,40 @@ __device__ __noinline__ void wg_qr_r(double* S_, int ld_, int M_, int n_, double
 // column of E is staged in LDS, the owners of the block's tiles pass them through LDS scratches to 16 threads per
 // column tile for the 16 x 16 substitution, and every wave updates its remaining tiles with rank-16 MFMAs).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int TS_SCR = BS_T * 16 * LU_LD;               // doubles: the staged block column (n <= 160 rows), then the ten scratches
+
+// threads 0 .. 16 nct - 1: X = E11^{-1} Y for column (tid & 15) of the tile in scratch (tid >> 4)
 template <bool LOWER>
 __device__ __noinline__ void tri_trsm_all(int k0_, int nb_, int nct_) {
     const int k0 = uni(k0_), nb = uni(nb_), nct = uni(nct_);
     if ((int)threadIdx.x >= 16 * nct) return;
     const double* const panel = g_lds;
-    double* const scratch = g_lds + BS_SCR + (threadIdx.x >> 4) * 16 * LU_LD;
+    double* const scratch = g_lds + TS_SCR + (threadIdx.x >> 4) * 16 * LU_LD;
     const int lo = threadIdx.x & 15;
     double x[LU_NB];
 #pragma unroll
     for (int j = 0; j < LU_NB; ++j) x[j] = j < nb ? scratch[j * LU_LD + lo] : 0.0;
-    if (LOWER) {
-#pragma unroll
-        for (int j = 0; j < LU_NB; ++j) {
-            int pj = (k0 + j) * LU_LD;
-            if (j > 0) asm("" : "+v"(pj) : "v"(x[j - 1]));                // (see lu_trsm_lower: keeps the reads from piling up)
-            double sacc = x[j];
-#pragma unroll
-            for (int i = 0; i < j; ++i) sacc = fma(-panel[pj + i], x[i], sacc);
-            x[j] = j < nb ? sacc * g_rdiag[j] : 0.0;
-        }
-    } else {
-#pragma unroll
-        for (int j = LU_NB - 1; j >= 0; --j) {
-            int pj = (k0 + j) * LU_LD;
-            if (j < LU_NB - 1) asm("" : "+v"(pj) : "v"(x[j + 1]));
-            double sacc = x[j];
-#pragma unroll
-            for (int i = j + 1; i < LU_NB; ++i)
-                if (i < nb) sacc = fma(-panel[pj + i], x[i], sacc);
-            x[j] = j < nb ? sacc * g_rdiag[j] : 0.0;
-        }
-    }
+    trsm16<LOWER, false>(x, panel + k0 * LU_LD, nb, g_rdiag);
 #pragma unroll
     for (int j = 0; j < LU_NB; ++j) scratch[j * LU_LD + lo] = x[j];
 }
 
+// (Two ways of hiding the per-block global round trip of the staging were built and measured slower: the next block column
+// prefetched into registers across the block, and waves 3-7 staging while waves 0-2 substitute -- both push this function
+// past 256 registers, and a spill reload in the MFMA loop waits for every outstanding load.)
 template <bool LOWER>
-__device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int trans_, double* Bm_, int ldb_, int n_, int nr_) {
+__device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int trans_, double* Bm_, int ldb_, int n_, int nr_,
+                                               double* ws_end_) {
     auto* const T = uni_g(T_);
     auto* const Bm = uni_g(Bm_);
+    auto* const ws_end = uni_g(ws_end_);
+    (void)ws_end;
+    RK_STAMP_DECL(ws_end);
     const int ldt = uni(ldt_), trans = uni(trans_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
     const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6)), lo = lane & 15, hi = lane >> 4;
     const int nbk = (n + 15) >> 4, nct = (nr + 15) >> 4;
     double* const panel = g_lds;
-    double* const scr = g_lds + BS_SCR;
+    double* const scr = g_lds + TS_SCR;
     d4 t[BS_Q];
 #pragma unroll
     for (int q = 0; q < BS_Q; ++q) {
@@ -446,9 +438,10 @@ __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int t
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int row = 16 * rb + 4 * v + hi, col = 16 * ct + lo;
-            double y = Bm[min(row, n - 1) * ldb + min(col, nr - 1)];
-            asm("" : "+v"(y));
-            t[q][v] = (row < n && col < nr) ? y : 0.0;
+            // clamped, unconditional and UNMASKED: all loads are in flight together (a select or an asm barrier behind a
+            // load makes hipcc wait for it at once -- 52 serialised round trips per solve).  A row / column past the end
+            // holds a copy of the last one: finite values that only meet zero multipliers and are never stored.
+            t[q][v] = Bm[min(row, n - 1) * ldb + min(col, nr - 1)];
         }
     }
     for (int kk = 0; kk < nbk; ++kk) {
@@ -476,10 +469,12 @@ __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int t
             }
         }
         __syncthreads();
+        RK_STAMP(11);
         if (threadIdx.x < nb) g_rdiag[threadIdx.x] = 1.0 / panel[(k0 + threadIdx.x) * LU_LD + threadIdx.x];
         __syncthreads();
         tri_trsm_all<LOWER>(k0, nb, nct);
         __syncthreads();
+        RK_STAMP(12);
 #pragma unroll
         for (int q = 0; q < BS_Q; ++q) {
             const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
@@ -497,6 +492,7 @@ __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int t
                 }
             }
         }
+        RK_STAMP(13);
     }
 #pragma unroll
     for (int q = 0; q < BS_Q; ++q) {
@@ -508,6 +504,7 @@ __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int t
         }
     }
     __syncthreads();
+    RK_STAMP(10);
 }
 
 // any size: one thread per right-hand-side column, everything in global memory (slow; beyond 160 x 160 only)
@@ -531,8 +528,9 @@ __device__ __noinline__ void wg_tri_solve_slow(const double* T_, int ldt_, int t
 }
 
 template <bool LOWER>
-__device__ __forceinline__ void wg_tri_solve(const double* T, int ldt, int trans, double* Bm, int ldb, int n, int nr) {
-    if (n <= 16 * BS_T && nr <= 16 * BS_T) wg_tri_solve_regs<LOWER>(T, ldt, trans, Bm, ldb, n, nr);
+__device__ __forceinline__ void wg_tri_solve(const double* T, int ldt, int trans, double* Bm, int ldb, int n, int nr,
+                                             double* ws_end = nullptr) {
+    if (n <= 16 * BS_T && nr <= 16 * BS_T) wg_tri_solve_regs<LOWER>(T, ldt, trans, Bm, ldb, n, nr, ws_end);
     else wg_tri_solve_slow<LOWER>(T, ldt, trans, Bm, ldb, n, nr);
 }
 
@@ -701,7 +699,7 @@ __device__ __forceinline__ void dense_sqrt_gain(const DenseArgs& a, const DenseS
     RK_STAMP(1);
     wg_gemm(gemm_op(w.A3, p, w.A2, p, false, w.A1, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
     RK_STAMP(2);
-    wg_tri_solve<false>(Lp, p, 1, w.A3, p, p, p);                                                          // G^T
+    wg_tri_solve<false>(Lp, p, 1, w.A3, p, p, p, RK_STAMP_TRI ? ws_end : nullptr);                              // G^T
     RK_STAMP(3);
     wg_gemv<false>(w.mup, a.Q, p, mu_f, p, p, nullptr, 0.0, 1.0);
     // J^T = I - Q^T G^T into w.A1 (square_root.py:215-216)
@@ -759,7 +757,7 @@ __global__ void __launch_bounds__(DT) dense_sqrt_bwd_mv_kernel(DenseArgs a) {
         RK_STAMP(5);
         dense_sqrt_mean(w, mu_f, mu_f, p);                                                    // square_root.py:211-212
         RK_STAMP(6);
-        wg_qr_r(w.S, p, 3 * p, p, ws_end);
+        wg_qr_r(w.S, p, 3 * p, p, RK_STAMP_TRI ? nullptr : ws_end);
         RK_STAMP(7);
         wg_transpose(Lf, p, w.S, p, p, p, 1);
         RK_STAMP(8);
