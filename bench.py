@@ -206,8 +206,12 @@ def main():
     W, x0, theta, prior = make_problem(ra, rank)
     plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, x0, 0.0, T_MAX, N_STEPS, ra.interrogate.interrogate_kramer, prior,
                         device=dev, traj_offset=rank * N_TRAJ, theta=theta)
+    # the warm-up solves run with the per-launch event brackets ON so that the handle's event pool is filled before the timed
+    # region (no hipEventCreate inside it); re-enabling clears the recorded entries and keeps the pool
+    dev.profile_enable(True, keep=True)
     for _ in range(args.warmup):
         plan.mv(None)
+    dev.sync()
     # ---- timed region: exactly K solves, inputs/outputs resident in HBM.  HIP events bracket every kernel launch on
     # the library's stream during these K solves (two hipEventRecord per launch, no synchronisation); they are read
     # after the closing barrier and give the per-kernel durations the roofline figures use ----
@@ -268,9 +272,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_traj_step": a_dom},
-            "roofline_solve": {"bound": "hbm", "achieved": (a_fwd + a_bwd) * units / (solve_ms * 1e-3) / 1e9,
+            # the whole solve against the HBM roof: `frac` divides by the wall-clock ms_per_step of the timed region (what the
+            # driver's clock sees); `frac_kernel_sum` by the sum of the kernels' HIP-event durations (no launch gaps)
+            "roofline_solve": {"bound": "hbm", "achieved": (a_fwd + a_bwd) * units / (wall / args.steps) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": (a_fwd + a_bwd) * units / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "frac": (a_fwd + a_bwd) * units / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
+                               "frac_kernel_sum": (a_fwd + a_bwd) * units / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_traj_step": a_fwd + a_bwd},
         }
         # why the dominant kernel sits far below the HBM roof: one dependent chain per wave

@@ -97,6 +97,7 @@ int         rk_free(rk_handle h, void* dptr);
 int         rk_memset(rk_handle h, void* dptr, int value, size_t bytes);
 int         rk_h2d(rk_handle h, void* dst_dev, const void* src_host, size_t bytes);   /* synchronous */
 int         rk_d2h(rk_handle h, void* dst_host, const void* src_dev, size_t bytes);   /* synchronous */
+int         rk_d2d(rk_handle h, void* dst_dev, const void* src_dev, size_t bytes);    /* asynchronous, on the handle's stream */
 int         rk_sync(rk_handle h);
 
 /* HIP-event timing on the handle's stream (the stream every kernel of this library is launched on). */

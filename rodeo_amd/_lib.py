@@ -75,6 +75,7 @@ SIGNATURES = {
     "rk_memset": (C.c_int, [_H, _P, C.c_int, C.c_size_t]),
     "rk_h2d": (C.c_int, [_H, _P, _P, C.c_size_t]),
     "rk_d2h": (C.c_int, [_H, _P, _P, C.c_size_t]),
+    "rk_d2d": (C.c_int, [_H, _P, _P, C.c_size_t]),
     "rk_sync": (C.c_int, [_H]),
     "rk_timer_start": (C.c_int, [_H]),
     "rk_timer_stop": (C.c_int, [_H, C.POINTER(_D)]),

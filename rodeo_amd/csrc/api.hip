@@ -6,6 +6,7 @@
 #include "common.hpp"
 
 namespace rk {
+constexpr size_t RK_PROFILE_KEEP_MAX = 1 << 16;
 
 static thread_local char g_err[1024] = "";
 
@@ -24,6 +25,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 
 LaunchTimer::LaunchTimer(rk_handle h_, const char* name) : h(h_), on(h_->profile), idx(0) {
     if (!on) return;
+    // keep mode (rk_profile_enable(h, 2)) accumulates over calls: bounded, so that a caller that forgets to switch it off
+    // neither grows the entry list nor the event pool without limit -- launches past the bound are simply not bracketed
+    if (h->profile_keep && h->prof.size() >= RK_PROFILE_KEEP_MAX) { on = false; return; }
     auto get = [&]() -> hipEvent_t {
         if (h->event_used == h->event_pool.size()) {
             hipEvent_t e;
@@ -93,6 +97,7 @@ int rk_create(int device_id, rk_handle* out) {
     h->profile_keep = false;
     h->event_used = 0;
     h->comm = nullptr;
+    h->comm_scratch = nullptr;
     h->rank = 0;
     h->nranks = 1;
     RK_HIP(hipGetDeviceProperties(&h->prop, device_id));
@@ -108,6 +113,7 @@ int rk_destroy(rk_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->comm) { (void)ncclCommDestroy((ncclComm_t)h->comm); h->comm = nullptr; }
+    if (h->comm_scratch) { (void)hipFree(h->comm_scratch); h->comm_scratch = nullptr; }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(h->t0);
     (void)hipEventDestroy(h->t1);
@@ -167,6 +173,14 @@ int rk_d2h(rk_handle h, void* dst, const void* src, size_t bytes) {
     RK_HIP(hipSetDevice(h->device));
     RK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     RK_HIP(hipStreamSynchronize(h->stream));
+    return RK_OK;
+}
+
+int rk_d2d(rk_handle h, void* dst, const void* src, size_t bytes) {
+    RK_REQUIRE(h && ((dst && src) || !bytes), RK_ERR_INVALID, "rk_d2d: bad arguments");
+    if (!bytes) return RK_OK;
+    RK_HIP(hipSetDevice(h->device));
+    RK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream));
     return RK_OK;
 }
 
@@ -241,6 +255,7 @@ int rk_comm_init(rk_handle h, int rank, int nranks, const void* uid128) {
     memcpy(&id, uid128, sizeof(id));
     ncclComm_t comm;
     RK_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
+    if (!h->comm_scratch) RK_HIP(hipMalloc((void**)&h->comm_scratch, sizeof(double)));      // rk_comm_barrier's word, on h->device
     h->comm = (void*)comm;
     h->rank = rank;
     h->nranks = nranks;
@@ -253,6 +268,11 @@ int rk_comm_destroy(rk_handle h) {
         RK_HIP(hipStreamSynchronize(h->stream));
         RK_NCCL(ncclCommDestroy((ncclComm_t)h->comm));
         h->comm = nullptr;
+    }
+    if (h->comm_scratch) {
+        RK_HIP(hipSetDevice(h->device));
+        RK_HIP(hipFree(h->comm_scratch));
+        h->comm_scratch = nullptr;
     }
     return RK_OK;
 }
@@ -282,9 +302,10 @@ int rk_allreduce_max_f64(rk_handle h, const double* send, double* recv, size_t c
 int rk_comm_barrier(rk_handle h) {
     RK_REQUIRE(h, RK_ERR_INVALID, "rk_comm_barrier: null handle");
     if (!h->comm) { RK_HIP(hipStreamSynchronize(h->stream)); return RK_OK; }
-    // a 1-element all-reduce on a scratch word, then wait: every rank has reached this point
-    static thread_local double* scratch = nullptr;
-    if (!scratch) RK_HIP(hipMalloc((void**)&scratch, sizeof(double)));
+    // a 1-element all-reduce on the handle's scratch word (allocated by rk_comm_init on the handle's device, freed by
+    // rk_comm_destroy), then wait: every rank has reached this point
+    double* const scratch = h->comm_scratch;
+    RK_REQUIRE(scratch, RK_ERR_INVALID, "rk_comm_barrier: communicator without scratch word");
     RK_HIP(hipMemsetAsync(scratch, 0, sizeof(double), h->stream));
     RK_NCCL(ncclAllReduce(scratch, scratch, 1, ncclDouble, ncclSum, (ncclComm_t)h->comm, h->stream));
     RK_HIP(hipStreamSynchronize(h->stream));

@@ -21,6 +21,7 @@ struct rk_handle_s {
     std::vector<hipEvent_t> event_pool;       // reused events
     size_t event_used;
     void* comm;                               // ncclComm_t (opaque here)
+    double* comm_scratch;                     // one device word for rk_comm_barrier, owned with the communicator
     int rank, nranks;
     hipDeviceProp_t prop;
 };

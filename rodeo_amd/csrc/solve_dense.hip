@@ -1430,7 +1430,7 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
         for (int n = 0; n < a.N; ++n) {
             g.n = n;
             const int rc = user_dense_interrogate(h, c, g);
-            if (rc) return rc;
+            if (rc) { t.stop(); return rc; }             // (the bracket's stop event must exist for rk_profile_last)
             a.n0 = n;
             hipLaunchKernelGGL((dense_fwd_kernel<2, true>), dim3(a.B), dim3(DT), 0, h->stream, a);
         }

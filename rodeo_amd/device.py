@@ -112,6 +112,16 @@ class DeviceArray:
         if self.nbytes:
             _lib.check(self.dev.lib.rk_h2d(self.dev.h, self.ptr, host.ctypes.data_as(C.c_void_p), self.nbytes))
 
+    def copy_from(self, other, count=None):
+        """Device-to-device copy of the first ``count`` elements of ``other`` (default: all) into this buffer's start; asynchronous
+        on the handle's stream (``rk_d2d``)."""
+        count = int(np.prod(other.shape, dtype=np.int64)) if count is None else int(count)
+        nb = count * self.dtype.itemsize
+        if other.dtype != self.dtype or nb > self.nbytes or nb > other.nbytes:
+            raise ValueError("copy_from: dtype / size mismatch")
+        if nb:
+            _lib.check(self.dev.lib.rk_d2d(self.dev.h, self.ptr, other.ptr, nb))
+
     def slice0_host(self, i):
         """Download only the i-th slice along the leading axis."""
         out = np.empty(self.shape[1:], self.dtype)

@@ -53,6 +53,30 @@ def default_rdzv_dir(env=None):
     return os.path.join(tempfile.gettempdir(), "rk_rdzv_" + tag)
 
 
+def _private_dir(path):
+    """
+    The rendezvous directory holds rank 0's address AND the nonce that authenticates the handshake, under a predictable
+    name in /tmp when a launcher gives no RK_RDZV_DIR: it must be ours alone.  Created with mode 0700; an existing one is
+    refused unless it is a real directory (no symlink) owned by this user and closed to group and others.
+    """
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    except FileNotFoundError:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        try:
+            os.mkdir(path, 0o700)
+        except FileExistsError:
+            pass
+    st = os.lstat(path)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():
+        raise PermissionError(f"rendezvous directory {path} is not a directory owned by uid {os.getuid()}")
+    if st.st_mode & 0o077:
+        os.chmod(path, 0o700)                       # ours, but open: close it (a directory another rank of ours just made)
+
+
 class HostGroup:
     """rank / world + bcast, allgather, allreduce, barrier over a TCP star through rank 0."""
 
@@ -66,7 +90,7 @@ class HostGroup:
         if world == 1:
             return
         rdzv_dir = rdzv_dir or default_rdzv_dir()
-        os.makedirs(rdzv_dir, exist_ok=True)
+        _private_dir(rdzv_dir)
         path = os.path.join(rdzv_dir, "rank0.addr")
         deadline = time.monotonic() + self.timeout
         if rank == 0:

@@ -64,7 +64,7 @@ def basic(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate
     Xt = LazyMean(plan)                    # valid until the plan's next launch / update (SolvePlan.generation)
     ind = obs_index(t_min, t_max, n_steps, obs_times)             # basic.py:61-62
     if isinstance(obs_loglik, GaussianObsLoglik):
-        ll = gauss_obs_logpost(plan, obs_data, ind, obs_loglik.noise_sd).to_host()
+        ll = gauss_obs_logpost(plan, obs_data, ind, obs_loglik.noise_sd, reuse_out=True).to_host()
         return (ll if plan.batched else float(ll[0])), Xt
     # generic callable: fetch only the observed time slices
     rows = []

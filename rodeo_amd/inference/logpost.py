@@ -19,11 +19,13 @@ def obs_index(t_min, t_max, n_steps, obs_times):
     return np.searchsorted(sim_times, np.asarray(obs_times, dtype=np.float64)).astype(np.int32)
 
 
-def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10.0, n_prior=None, which="auto"):
+def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10.0, n_prior=None, which="auto",
+                      reuse_out=False):
     """
     ``plan``: a ``SolvePlan`` whose ``mv()`` / ``sim()`` has been launched.  ``obs_data`` (n_obs, d), ``obs_ind``
     (n_obs,) int; ``upars`` (B, k) optional unconstrained parameters whose first ``n_prior`` entries get a
-    N(0, prior_sd^2) prior.  Returns a DeviceArray of shape (B,) (call ``.to_host()``).
+    N(0, prior_sd^2) prior.  Returns a DeviceArray of shape (B,) (call ``.to_host()``): a fresh one, or -- with
+    ``reuse_out=True`` -- one of four buffers owned by the plan that later calls overwrite in turn.
     """
     dev = plan.dev
     obs = np.ascontiguousarray(obs_data, dtype=np.float64)
@@ -56,17 +58,21 @@ def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10
             d_up = cache["up"] = dev.to_device(upt)
         else:
             d_up.upload(upt)
-    # the result buffer comes from a small ring on the plan (a device allocation per call cost more than the kernel: 0.08 of
-    # C4's 0.32 ms per evaluation); a returned array is overwritten by the FOURTH call after it
-    ring = cache.setdefault("out_ring", [])
-    if len(ring) < 4 or tuple(ring[0].shape) != (plan.B,):
+    # The result is a fresh device array unless the caller opts into `reuse_out`: then it comes from a ring of four buffers on
+    # the plan (a device allocation per call cost more than the kernel: 0.08 of C4's 0.32 ms per evaluation) and is
+    # overwritten by the FOURTH reusing call after it -- for callers that read the result at once (FitzLogPosterior, basic).
+    if reuse_out:
+        ring = cache.setdefault("out_ring", [])
         if ring and tuple(ring[0].shape) != (plan.B,):
             ring.clear()
-        ring.append(dev.empty((plan.B,)))
-        out = ring[-1]
+            cache["out_calls"] = 0
+        n_call = cache.get("out_calls", 0)
+        cache["out_calls"] = n_call + 1
+        if len(ring) < 4:
+            ring.append(dev.empty((plan.B,)))
+        out = ring[n_call % 4]                  # call 5 reuses the buffer of call 1, call 6 that of call 2, ...
     else:
-        cache["out_next"] = (cache.get("out_next", 0) + 1) % 4
-        out = ring[cache["out_next"]]
+        out = dev.empty((plan.B,))
     _lib.check(dev.lib.rk_gauss_obs_logpost(dev.h, plan.B, plan.N, plan.d, plan.p, layout, state.ptr, d_obs.ptr,
                                             d_ind.ptr, ind.shape[0], float(noise_sd),
                                             d_up.ptr if d_up is not None else None, k, float(prior_sd), out.ptr))

@@ -277,7 +277,10 @@ class FitzLogPosterior:
         prior = self.ra.ibm_init((self.t_max - self.t_min) / self.N, 3, sigma)
         return theta, x0, prior
 
-    def __call__(self, upars, key):
+    def device(self, upars, key):
+        """The log-posteriors as a DEVICE array of shape (C,) -- what a sharded caller hands to the RCCL all-gather without a
+        round trip through the host (``shard.gather_scalars_device``).  One of four buffers of the plan, overwritten by the
+        fourth call after this one."""
         from .logpost import gauss_obs_logpost
         upars = np.asarray(upars, dtype=np.float64)
         if upars.shape != (self.C, 7):
@@ -285,6 +288,8 @@ class FitzLogPosterior:
         theta, x0, prior = self._constrain(upars)
         self.plan.update(ode_init=x0, prior_pars=prior, theta=theta)
         self.plan.sim(key)
-        lp = gauss_obs_logpost(self.plan, self.obs, self.ind, self.noise_sd, upars=upars, prior_sd=self.prior_sd,
-                               n_prior=5).to_host()
-        return lp, None
+        return gauss_obs_logpost(self.plan, self.obs, self.ind, self.noise_sd, upars=upars, prior_sd=self.prior_sd,
+                                 n_prior=5, reuse_out=True)
+
+    def __call__(self, upars, key):
+        return self.device(upars, key).to_host(), None

@@ -31,36 +31,66 @@ def shard(arr, rank, nranks, batched=True):
     return arr[lo:hi]
 
 
+def padded_width(n_total, nranks):
+    """Scalars per rank in the equal-width all-gather: ceil(n_total / nranks) (the largest shard of ``partition``)."""
+    return -(-int(n_total) // int(nranks))
+
+
+def trim_padded(flat, n_total, nranks):
+    """(nranks * width,) gathered with every shard padded to ``padded_width`` -> (n_total,) in global trajectory order."""
+    width = padded_width(n_total, nranks)
+    flat = np.asarray(flat, dtype=np.float64).reshape(nranks, width)
+    return np.concatenate([flat[r, :partition(n_total, r, nranks)[1] - partition(n_total, r, nranks)[0]]
+                           for r in range(nranks)])
+
+
 def gather_scalars(local, n_total, rank, nranks, dist=None):
     """
     All-gather per-trajectory scalars (n_local,) -> (n_total,) in global trajectory order over a HOST channel:
     ``dist`` is a ``rodeo_amd.hostgroup.HostGroup`` (standard-library TCP star, what bench.py and the scripts use) or a
-    ``torch.distributed``-like module / process group (any backend; gloo in the CPU tests).  Ragged shards are fine.
-    On GPUs with an RCCL communicator use ``RcclComm.allgather`` instead (device buffers, xGMI).
+    ``torch.distributed``-like module / process group (any backend; gloo in the CPU tests).  Ragged shards travel padded to
+    the common width ``padded_width`` and are trimmed on arrival -- the same scheme as ``gather_scalars_device`` (RCCL).
     """
     local = np.ascontiguousarray(local, dtype=np.float64)
+    lo, hi = partition(n_total, rank, nranks)
+    if local.shape != (hi - lo,):
+        raise ValueError(f"rank {rank} holds {local.shape} scalars, its shard has {hi - lo}")
     if nranks == 1:
         return local.copy()
+    width = padded_width(n_total, nranks)
+    buf = np.zeros(width)
+    buf[:hi - lo] = local
     if hasattr(dist, "allgather_f64"):                    # HostGroup
-        parts = dist.allgather_f64(local)
-        for r in range(nranks):
-            lo, hi = partition(n_total, r, nranks)
-            if parts[r].shape[0] != hi - lo:
-                raise ValueError(f"rank {r} sent {parts[r].shape[0]} scalars, its shard has {hi - lo}")
-        return np.concatenate(parts)
+        parts = dist.allgather_f64(buf)
+        if any(np.shape(p_) != (width,) for p_ in parts):
+            raise ValueError(f"a rank sent {[np.shape(p_) for p_ in parts]} scalars, the padded width is {width}")
+        return trim_padded(np.concatenate(parts), n_total, nranks)
     import torch
     import torch.distributed as tdist
     dist = dist or tdist
-    width = -(-int(n_total) // nranks)
-    buf = torch.zeros(width, dtype=torch.float64)
-    buf[:local.shape[0]] = torch.from_numpy(local)
     outs = [torch.zeros(width, dtype=torch.float64) for _ in range(nranks)]
-    dist.all_gather(outs, buf)
-    parts = []
-    for r in range(nranks):
-        lo, hi = partition(n_total, r, nranks)
-        parts.append(outs[r][:hi - lo].numpy())
-    return np.concatenate(parts)
+    dist.all_gather(outs, torch.from_numpy(buf))
+    return trim_padded(torch.cat(outs).numpy(), n_total, nranks)
+
+
+def gather_scalars_device(local_dev, n_total, rank, nranks, comm, device):
+    """
+    The same all-gather over RCCL / xGMI from a DEVICE array (n_local,) of this rank's scalars (e.g.
+    ``FitzLogPosterior.device``): ``rk_allgather_f64`` with every shard padded to ``padded_width`` in a device staging buffer
+    (equal counts are what ncclAllGather takes; the pad of a short shard is whatever the buffer held and is trimmed away),
+    one download of the result.  Ragged shards included; nothing passes through the host on the way in.
+    """
+    lo, hi = partition(n_total, rank, nranks)
+    if tuple(local_dev.shape) != (hi - lo,):
+        raise ValueError(f"rank {rank} holds {tuple(local_dev.shape)} scalars, its shard has {hi - lo}")
+    width = padded_width(n_total, nranks)
+    cache = device.__dict__.setdefault("_gather_bufs", {})
+    if cache.get("key") != (width, nranks):
+        cache["key"], cache["send"], cache["recv"] = (width, nranks), device.zeros((width,)), device.empty((nranks * width,))
+    send, recv = cache["send"], cache["recv"]
+    send.copy_from(local_dev, hi - lo)
+    comm.allgather(send, recv, width)
+    return trim_padded(recv.to_host(), n_total, nranks)
 
 
 def init_rccl_or_fail(device, group, deadline=90.0):

@@ -53,7 +53,7 @@ def c4(args):
     Y = rng.standard_normal((41, 2))
     def run():
         plan.sim(20242)
-        return gauss_obs_logpost(plan, Y, ind, np.sqrt(0.005), upars=upars, n_prior=5)
+        return gauss_obs_logpost(plan, Y, ind, np.sqrt(0.005), upars=upars, n_prior=5, reuse_out=True)
     ms = timeit(run, plan.dev, 5)
     a = (2 * 2 * 3 * 4 + 2 * 3) * 8
     plan.dev.profile_enable(True)

@@ -103,6 +103,18 @@ def test_chkrebtii_pseudo_marginal_logposterior(ra):
     np.testing.assert_allclose(lp, ref2, rtol=1e-12, atol=1e-9)
     with pytest.raises(ValueError):
         gauss_obs_logpost(plan, s["Y"], ind + 1000, sd)
+    # Ownership of the result.  Default: a fresh device array per call -- four kept results are still intact after a fifth
+    # call.  reuse_out=True: a ring of four buffers on the plan, call 5 reuses the buffer of call 1 (and only that one).
+    ups = [upars + 0.01 * k for k in range(5)]
+    want = [gauss_obs_logpost(plan, s["Y"], ind, sd, upars=u, n_prior=5).to_host() for u in ups]
+    kept = [gauss_obs_logpost(plan, s["Y"], ind, sd, upars=u, n_prior=5) for u in ups]
+    for k in range(5):
+        np.testing.assert_array_equal(kept[k].to_host(), want[k])
+    ring = [gauss_obs_logpost(plan, s["Y"], ind, sd, upars=u, n_prior=5, reuse_out=True) for u in ups]
+    assert ring[4].ptr == ring[0].ptr and len({r.ptr for r in ring[:4]}) == 4
+    for k in (1, 2, 3, 4):
+        np.testing.assert_array_equal(ring[k].to_host(), want[k])
+    np.testing.assert_array_equal(ring[0].to_host(), want[4])              # overwritten by the fifth call, as documented
 
 
 def test_lockstep_pseudo_marginal_chain_on_device(ra):

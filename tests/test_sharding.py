@@ -29,6 +29,47 @@ def test_partition_covers_everything():
     assert rs.shard(x, 1, 3, batched=False) is x
 
 
+def test_padded_ragged_gather_layout():
+    """The equal-width all-gather every channel uses (gloo, host TCP, RCCL): shards padded to ceil(n / G), trimmed on
+    arrival.  Three ranks, ten scalars (shards 4, 3, 3): whatever sits in the pads (NaN here, stale device memory over
+    RCCL) never reaches the result."""
+    n, g = 10, 3
+    w = rs.padded_width(n, g)
+    assert w == 4 and rs.padded_width(8192, 8) == 1024 and rs.padded_width(5, 8) == 1
+    want = np.arange(n, dtype=np.float64) * 1.5
+    sent = []
+    for r in range(g):
+        lo, hi = rs.partition(n, r, g)
+        buf = np.full(w, np.nan)
+        buf[:hi - lo] = want[lo:hi]
+        sent.append(buf)
+    np.testing.assert_array_equal(rs.trim_padded(np.concatenate(sent), n, g), want)
+    # the device variant packs through a staging buffer of that width and one rk_allgather_f64: same layout (fake device)
+
+    class Arr:
+        def __init__(self, a): self.a, self.shape = np.asarray(a, dtype=np.float64), np.shape(a)
+        def copy_from(self, other, count): self.a[:count] = other.a[:count]
+        def to_host(self): return self.a.copy()
+
+    class Dev:
+        def zeros(self, shape): return Arr(np.zeros(shape))
+        def empty(self, shape): return Arr(np.full(shape, np.nan))
+
+    class Comm:                                           # what ncclAllGather does, with the other ranks' buffers filled in
+        def __init__(self, rank): self.rank = rank
+        def allgather(self, send, recv, count):
+            for r in range(g):
+                recv.a[r * count:(r + 1) * count] = send.a if r == self.rank else sent[r]
+    for r in range(g):
+        lo, hi = rs.partition(n, r, g)
+        full = rs.gather_scalars_device(Arr(want[lo:hi]), n, r, g, Comm(r), Dev())
+        np.testing.assert_array_equal(full, want)
+    with pytest.raises(ValueError):
+        rs.gather_scalars_device(Arr(want[:2]), n, 0, g, Comm(0), Dev())
+    with pytest.raises(ValueError):
+        rs.gather_scalars(want[:2], n, 0, g, None)
+
+
 def _logpost_of_shard(lo, hi, seed):
     """Per-draw scalar of a chkrebtii solve_sim for global draws [lo, hi) (oracle stands in for the GPU on CPU)."""
     import functools
@@ -133,3 +174,26 @@ def test_spawn_ranks_failed_rank_ends_the_job(tmp_path):
     ok = tmp_path / "ok.py"
     ok.write_text("import os\nassert os.environ['WORLD_SIZE'] == '2' and os.path.isdir(os.environ['RK_RDZV_DIR'])\n")
     assert spawn_ranks([sys.executable, str(ok)], 2) == 0
+
+
+def test_rendezvous_directory_is_private(tmp_path):
+    """The rendezvous directory carries the handshake nonce: created 0700, an open one of ours is closed, a symlink or a
+    directory of another owner is refused (rodeo_amd/hostgroup.py _private_dir)."""
+    import stat
+    from rodeo_amd import hostgroup as hg
+    d = tmp_path / "rdzv"
+    hg._private_dir(str(d))
+    assert stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    os.chmod(d, 0o755)
+    hg._private_dir(str(d))
+    assert stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    target = tmp_path / "elsewhere"
+    target.mkdir()
+    link = tmp_path / "link"
+    os.symlink(target, link)
+    with pytest.raises(PermissionError):
+        hg._private_dir(str(link))
+    f = tmp_path / "file"
+    f.write_text("x")
+    with pytest.raises(PermissionError):
+        hg._private_dir(str(f))
