@@ -98,6 +98,8 @@ int rk_create(int device_id, rk_handle* out) {
     h->event_used = 0;
     h->comm = nullptr;
     h->comm_scratch = nullptr;
+    h->op_scratch = nullptr;
+    h->op_scratch_bytes = 0;
     h->rank = 0;
     h->nranks = 1;
     RK_HIP(hipGetDeviceProperties(&h->prop, device_id));
@@ -114,6 +116,7 @@ int rk_destroy(rk_handle h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->comm) { (void)ncclCommDestroy((ncclComm_t)h->comm); h->comm = nullptr; }
     if (h->comm_scratch) { (void)hipFree(h->comm_scratch); h->comm_scratch = nullptr; }
+    if (h->op_scratch) { (void)hipFree(h->op_scratch); h->op_scratch = nullptr; }
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(h->t0);
     (void)hipEventDestroy(h->t1);

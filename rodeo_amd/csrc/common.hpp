@@ -22,6 +22,8 @@ struct rk_handle_s {
     size_t event_used;
     void* comm;                               // ncclComm_t (opaque here)
     double* comm_scratch;                     // one device word for rk_comm_barrier, owned with the communicator
+    void* op_scratch;                         // grow-only device scratch of the large-block per-step operators
+    size_t op_scratch_bytes;
     int rank, nranks;
     hipDeviceProp_t prop;
 };

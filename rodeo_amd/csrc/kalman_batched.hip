@@ -5,22 +5,9 @@
 // These entry points serve unit parity and ad-hoc use; the timed solver path is the fused kernels of
 // solve_small.hip / solve_dense.hip.  NumPy mirrors: oracle/kalman_ops.py, oracle/sqrt_ops.py.
 #include "common.hpp"
+#include "kalman_op_args.hpp"
 
 namespace rk {
-
-enum OpId { OP_PREDICT, OP_UPDATE, OP_FILTER, OP_SMOOTH_MV, OP_SMOOTH_SIM, OP_SMOOTH, OP_FORECAST, OP_SMOOTH_COND };
-
-struct OpArgs {
-    int n, p, m, op, sqrt_form;
-    // inputs (NULL -> zeros)
-    const double *mean_state_past, *var_state_past, *mean_state, *wgt_state, *var_state;
-    const double *mean_state_pred, *var_state_pred, *x_meas, *mean_meas, *wgt_meas, *var_meas;
-    const double *mean_state_next, *var_state_next, *mean_state_filt, *var_state_filt, *x_state_next;
-    // outputs
-    double *o_mean_pred, *o_var_pred, *o_mean_filt, *o_var_filt;
-    double *o_mean_smooth, *o_var_smooth, *o_mean_sim, *o_var_sim;
-    double *o_mean_fore, *o_var_fore, *o_wgt_cond, *o_mean_cond, *o_var_cond;
-};
 
 template <int MAXN>
 struct Mat {
@@ -403,11 +390,7 @@ static int launch_op(rk_handle h, const rk_op_cfg* c, OpArgs& a, int op) {
     const dim3 grid(div_up(a.n, 64)), block(64);
     if (a.p <= 8) hipLaunchKernelGGL((kalman_op_kernel<8>), grid, block, 0, h->stream, a);
     else if (a.p <= 16) hipLaunchKernelGGL((kalman_op_kernel<16>), grid, block, 0, h->stream, a);
-    else {
-        set_error("batched per-step operators support n_state <= 16 (got %d); larger blocks go through the dense "
-                  "solver path", a.p);
-        return RK_ERR_UNSUPPORTED;
-    }
+    else return dense_op_launch(h, a);       // one workgroup per item on the dense building blocks (solve_dense_ops.hpp)
     RK_HIP(hipGetLastError());
     return RK_OK;
 }

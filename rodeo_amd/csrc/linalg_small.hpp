@@ -183,4 +183,45 @@ __device__ __forceinline__ void psd_factor(const double (&A)[P][P], double (&L)[
     }
 }
 
+// Symmetric M x M eigendecomposition by cyclic Jacobi rotations (M <= 3: eight sweeps are far past convergence):
+// A is destroyed, w <- eigenvalues, V <- eigenvectors in its columns.  For the log-density rule of utils.py:60-78
+// (jnp.linalg.eigh, eigenvalues with |w| <= 1e-8 dropped); the value does not depend on the order or signs returned.
+template <int M>
+__device__ __forceinline__ void sym_eig_jacobi(double (&A)[M][M], double (&w)[M], double (&V)[M][M]) {
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+        for (int p_ = 0; p_ < M - 1; ++p_)
+#pragma unroll
+            for (int q = p_ + 1; q < M; ++q) {
+                const double apq = A[p_][q];
+                const bool go = apq != 0.0;
+                const double theta = go ? (A[q][q] - A[p_][p_]) / (2.0 * apq) : 0.0;
+                const double t = go ? (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)) : 0.0;
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < M; ++k) {                    // A <- A J
+                    const double akp = A[k][p_], akq = A[k][q];
+                    A[k][p_] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < M; ++k) {                    // A <- J^T A ; V <- V J
+                    const double apk = A[p_][k], aqk = A[q][k];
+                    A[p_][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                    const double vkp = V[k][p_], vkq = V[k][q];
+                    V[k][p_] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) w[i] = A[i][i];
+}
+
+
 }  // namespace rk

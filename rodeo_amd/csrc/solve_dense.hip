@@ -1289,6 +1289,7 @@ __global__ void __launch_bounds__(DT) dense_bwd_sim_kernel(DenseArgs a) {
 }  // namespace rk
 
 #include "solve_dense_sqrt.hpp"
+#include "solve_dense_ops.hpp"
 
 namespace rk {
 

@@ -159,46 +159,6 @@ __global__ void gauss_logpost_kernel(int B, int n_steps, int D, int P, int tile,
 // With STORE (fenrir.py:236-258, for fenrir's solve_mv) the backward filter's predicted and updated moments of every
 // time and the Markov weights A_n are kept in `states`: per (time n, block) an item of 3 P^2 + 2 P doubles
 // [m_pred (P), S_pred (P^2), m_filt (P), S_filt (P^2), A (P^2)], batch-minor.
-// Symmetric M x M eigendecomposition by cyclic Jacobi rotations (M <= 3: eight sweeps are far past convergence):
-// A is destroyed, w <- eigenvalues, V <- eigenvectors in its columns.  For the log-density rule of utils.py:60-78
-// (jnp.linalg.eigh, eigenvalues with |w| <= 1e-8 dropped); the value does not depend on the order or signs returned.
-template <int M>
-__device__ __forceinline__ void sym_eig_jacobi(double (&A)[M][M], double (&w)[M], double (&V)[M][M]) {
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-        for (int j = 0; j < M; ++j) V[i][j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 8; ++sweep) {
-#pragma unroll
-        for (int p_ = 0; p_ < M - 1; ++p_)
-#pragma unroll
-            for (int q = p_ + 1; q < M; ++q) {
-                const double apq = A[p_][q];
-                const bool go = apq != 0.0;
-                const double theta = go ? (A[q][q] - A[p_][p_]) / (2.0 * apq) : 0.0;
-                const double t = go ? (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)) : 0.0;
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-#pragma unroll
-                for (int k = 0; k < M; ++k) {                    // A <- A J
-                    const double akp = A[k][p_], akq = A[k][q];
-                    A[k][p_] = c * akp - sn * akq;
-                    A[k][q] = sn * akp + c * akq;
-                }
-#pragma unroll
-                for (int k = 0; k < M; ++k) {                    // A <- J^T A ; V <- V J
-                    const double apk = A[p_][k], aqk = A[q][k];
-                    A[p_][k] = c * apk - sn * aqk;
-                    A[q][k] = sn * apk + c * aqk;
-                    const double vkp = V[k][p_], vkq = V[k][q];
-                    V[k][p_] = c * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + c * vkq;
-                }
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < M; ++i) w[i] = A[i][i];
-}
-
 // MO = n_bobs (observations per block, fenrir.py:106-122): obs (n_obs, d, MO), obs_w (n_obs, d, MO, P), obs_v (n_obs, d, MO, MO)
 template <int P, bool STORE, int MO>
 __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const double* __restrict__ obs,
@@ -588,6 +548,11 @@ int user_interrogate(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, dou
 // fused square-root solver (solve_sqrt.hip)
 int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode);
 
+// fenrir with kalman_type = square-root (fenrir_sqrt.hip)
+size_t fenrir_sqrt_item_doubles(int p);
+int fenrir_sqrt_launch(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, const double* obs, const double* obs_w,
+                       const double* obs_v, const int32_t* obs_ind, int n_obs, int n_bobs, double* logdens, double* states);
+
 // MFMA-tile path for n_bstate = 4 (solve_tile4.hip)
 bool tile4_supported(const rk_solve_cfg* c, int mode);
 int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
@@ -759,8 +724,20 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
                        int32_t n_obs, int32_t n_bobs, double* logdens) {
     RK_REQUIRE(h && c && in && out && obs && obs_weight && obs_var && obs_ind && logdens, RK_ERR_INVALID,
                "rk_fenrir_backward: null argument");
-    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_backward: kalman_type must be standard");
     RK_REQUIRE(n_bobs >= 1 && n_bobs <= 3, RK_ERR_UNSUPPORTED, "rk_fenrir_backward: n_bobs in 1..3, got %d", n_bobs);
+    if (c->kalman_type == RK_KALMAN_SQRT) {
+        // fenrir.py:292-296: every step map from square_root.py; the filtered FACTORS of the square-root forward pass
+        // (batch-minor, solve_sqrt.hip) are all it needs -- the predicted ones are re-evaluated (fenrir_sqrt.hip)
+        RK_REQUIRE(out->mean_state && out->var_state && n_obs >= 0, RK_ERR_INVALID,
+                   "rk_fenrir_backward (square-root): out->mean_state / var_state of rk_solve_filter are null");
+        SolveArgs as;
+        int rcs = make_args(c, in, out, as);
+        if (rcs) return rcs;
+        RK_HIP(hipSetDevice(h->device));
+        RK_HIP(hipMemsetAsync(logdens, 0, sizeof(double) * (size_t)c->n_traj, h->stream));
+        return fenrir_sqrt_launch(h, c, as, obs, obs_weight, obs_var, obs_ind, n_obs, n_bobs, logdens, nullptr);
+    }
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_backward: unknown kalman_type %d", c->kalman_type);
     if (n_bobs == 1 && !(c->flags & (RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)) && tile3_supported(c, RK_MODE_FILTER)) {
         // the filter ran on the MFMA-tile path: out->var_state holds the RK_LAYOUT_TILE3 tiles, predicted moments are
         // re-evaluated from the filtered ones (solve_tile3.hip, fenrir_bwd_tile3_kernel)
@@ -809,7 +786,8 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
 int rk_fenrir_workspace_bytes(const rk_solve_cfg* c, size_t* bytes) {
     RK_REQUIRE(c && bytes, RK_ERR_INVALID, "rk_fenrir_workspace_bytes: null argument");
     const size_t p = (size_t)c->n_bstate;
-    *bytes = sizeof(double) * (size_t)(c->n_steps + 1) * c->n_block * (3 * p * p + 2 * p) * c->n_traj;
+    const size_t item = c->kalman_type == RK_KALMAN_SQRT ? fenrir_sqrt_item_doubles(c->n_bstate) : 3 * p * p + 2 * p;
+    *bytes = sizeof(double) * (size_t)(c->n_steps + 1) * c->n_block * item * c->n_traj;
     return RK_OK;
 }
 
@@ -818,7 +796,16 @@ int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
                        int32_t n_obs, int32_t n_bobs, void* workspace) {
     RK_REQUIRE(h && c && in && out && obs && obs_weight && obs_var && obs_ind && workspace, RK_ERR_INVALID,
                "rk_fenrir_solve_mv: null argument");
-    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_solve_mv: kalman_type must be standard");
+    if (c->kalman_type == RK_KALMAN_SQRT) {                          // fenrir.py:421-426 (fenrir_sqrt.hip)
+        RK_REQUIRE(out->mean_state && out->var_state && n_obs >= 0, RK_ERR_INVALID,
+                   "rk_fenrir_solve_mv (square-root): out->mean_state / var_state of rk_solve_filter are null");
+        SolveArgs as;
+        int rcs = make_args(c, in, out, as);
+        if (rcs) return rcs;
+        RK_HIP(hipSetDevice(h->device));
+        return fenrir_sqrt_launch(h, c, as, obs, obs_weight, obs_var, obs_ind, n_obs, n_bobs, nullptr, (double*)workspace);
+    }
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED, "rk_fenrir_solve_mv: unknown kalman_type %d", c->kalman_type);
     RK_REQUIRE((c->flags & RK_FLAG_STORE_PRED) && (c->flags & RK_FLAG_BATCH_MINOR) && out->mean_state && out->var_state &&
                out->mean_pred && out->var_pred, RK_ERR_INVALID,
                "rk_fenrir_solve_mv needs the batch-minor filtered AND predicted moments of rk_solve_filter "

@@ -10,9 +10,10 @@ Same signature as the reference.  Extension: a leading batch axis on ``ode_init`
 (observations are shared) returns an array (B,).  Observations per block: n_bobs = 1 .. 3 (``obs_data`` (n_obs, n_block,
 n_bobs), ``obs_weight`` (n_obs, n_block, n_bobs, n_bstate), ``obs_var`` (n_obs, n_block, n_bobs, n_bobs), fenrir.py:106-122);
 vector observations run on the lane-per-trajectory kernels (LU update, eigendecomposition log-density of utils.py:60-78).
-Restriction of this build: ``kalman_type="standard"`` -- the reference's square-root variant hands the Cholesky FACTOR of
-the forecast variance to ``multivariate_normal_logpdf`` as if it were the covariance (fenrir.py:63-70 with
-square_root.py's forecast), so its value is not a log-likelihood; it is not reproduced.
+``kalman_type="square-root"`` (fenrir.py:292-296, 421-426): ``prior_pars[1]`` and ``obs_var`` are lower factors, the forward
+pass is the square-root filter and every backward step map comes from ``square_root.py``; its ``forecast`` squares the
+factor before the log-density sees it (square_root.py:343-344), so the value is the same log-likelihood as in covariance
+form for ``L L^T`` inputs (tests).  Lane-per-trajectory kernels (``fenrir_sqrt.hip``), n_bstate 2 .. 6.
 """
 import ctypes as C
 import numpy as np
@@ -25,14 +26,15 @@ def fenrir(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogat
            obs_data, obs_times, obs_weight, obs_var, kalman_type="standard", **params):
     if kalman_type not in ("standard", "square-root"):
         raise NotImplementedError                                   # fenrir.py:293-298
-    if kalman_type != "standard":
-        raise NotImplementedError("fenrir on the device: kalman_type='standard' only in this build")
     obs, D, Om, n_bobs = _check_obs(obs_data, obs_weight, obs_var)
     ind = obs_index(t_min, t_max, n_steps, obs_times)             # fenrir.py:118-120
     if np.any(np.diff(ind) < 0):
         raise ValueError("obs_times must be ascending")
-    plan = _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params,
-                     tiles_ok=n_bobs == 1)
+    if kalman_type == "square-root":
+        plan = cached_plan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, **params)
+    else:
+        plan = _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params,
+                         tiles_ok=n_bobs == 1)
     if D.shape[1:] != (plan.d, n_bobs, plan.p):
         raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, n_bobs, {plan.p})")
     plan.filter(key)
@@ -91,15 +93,14 @@ def solve_mv(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrog
     """
     if kalman_type not in ("standard", "square-root"):
         raise NotImplementedError                                   # fenrir.py:421-426
-    if kalman_type != "standard":
-        raise NotImplementedError("fenrir.solve_mv on the device: kalman_type='standard' only in this build")
     obs, D, Om, n_bobs = _check_obs(obs_data, obs_weight, obs_var)
     ind = obs_index(t_min, t_max, n_steps, obs_times)
     if np.any(np.diff(ind) < 0):
         raise ValueError("obs_times must be ascending")
     from ..solve import SolvePlan
+    sq = kalman_type == "square-root"                               # (its forward pass is batch-minor and keeps no predictions)
     plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
-                     store_pred=True, batch_minor=True, **params)
+                     store_pred=not sq, batch_minor=not sq, **params)
     if D.shape[1:] != (plan.d, n_bobs, plan.p):
         raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, n_bobs, {plan.p})")
     plan.filter(key)

@@ -111,7 +111,7 @@ def test_chkrebtii_pseudo_marginal_logposterior(ra):
     for k in range(5):
         np.testing.assert_array_equal(kept[k].to_host(), want[k])
     ring = [gauss_obs_logpost(plan, s["Y"], ind, sd, upars=u, n_prior=5, reuse_out=True) for u in ups]
-    assert ring[4].ptr == ring[0].ptr and len({r.ptr for r in ring[:4]}) == 4
+    assert ring[4].ptr.value == ring[0].ptr.value and len({r.ptr.value for r in ring[:4]}) == 4
     for k in (1, 2, 3, 4):
         np.testing.assert_array_equal(ring[k].to_host(), want[k])
     np.testing.assert_array_equal(ring[0].to_host(), want[4])              # overwritten by the fifth call, as documented
@@ -432,3 +432,74 @@ def test_fenrir_vector_observations(ra, p, n_bobs):
     with pytest.raises(NotImplementedError):
         ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, prior, np.zeros((n_obs, 2, 4)), obs_times,
                             np.zeros((n_obs, 2, 4, p)), np.zeros((n_obs, 2, 4, 4)), theta=theta)
+
+
+@pytest.mark.parametrize("name,p,n_bobs", [("kramer", 3, 1), ("rodeo", 3, 1), ("kramer", 4, 1), ("kramer", 3, 2), ("rodeo", 5, 2),
+                                            ("kramer", 2, 1), ("kramer", 6, 3)])
+def test_fenrir_parity_square_root(ra, name, p, n_bobs):
+    """fenrir with kalman_type="square-root" (src/rodeo/inference/fenrir.py:292-296 with square_root.py:30-345: the forecast
+    returns the full variance, square_root.py:343-344): prior_pars[1] and obs_var are lower factors.  Device against the
+    oracle's square-root branch (1e-7), and -- exact measurement, the same model in both forms -- against the covariance
+    form's value for the L L^T inputs (1e-6); a batch, observations at both ends."""
+    from oracle import fenrir as ofen
+    N, t_max, B = 60, 3.0, 5
+    rng = np.random.default_rng(40 + p + n_bobs)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0 = init(np.array([-1., 1.]) + 0.05 * rng.standard_normal((B, 2)), 0.0, theta=theta)
+    Q, R = ra.ibm_init(t_max / N, p, np.array([.1, .1]))
+    Rh = np.linalg.cholesky(R)
+    obs_times = np.array([0.0, 0.75, 1.5, 2.2, 3.0])
+    n_obs = len(obs_times)
+    y = rng.standard_normal((n_obs, 2, n_bobs))
+    Dw = 0.3 * rng.standard_normal((n_obs, 2, n_bobs, p)); Dw[..., 0, 0] = 1.0
+    A = rng.standard_normal((n_obs, 2, n_bobs, n_bobs))
+    Om = 0.02 * (A @ np.swapaxes(A, -1, -2) + np.eye(n_bobs))
+    Oh = np.linalg.cholesky(Om)
+    g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+    args = (W, x0, 0.0, t_max, N)
+    val = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, (Q, Rh), y, obs_times, Dw, Oh, kalman_type="square-root",
+                              theta=theta)
+    ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, o, (Q, Rh), y, obs_times, Dw, Oh, kalman_type="square-root", theta=theta)
+    assert val.shape == (B,)
+    tol = 1e-7 if p <= 4 else 1e-5
+    np.testing.assert_allclose(val, ref, rtol=tol, atol=tol)
+    if name == "kramer" and p <= 4:
+        std = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, (Q, R), y, obs_times, Dw, Om, theta=theta)
+        np.testing.assert_allclose(val, std, rtol=1e-6, atol=1e-6)
+    one = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, W, x0[0], 0.0, t_max, N, g, (Q, Rh), y, obs_times, Dw, Oh,
+                              kalman_type="square-root", theta=theta[0])
+    assert isinstance(one, float) and abs(one - ref[0]) < tol * max(1.0, abs(ref[0]))
+
+
+@pytest.mark.parametrize("p,n_bobs", [(3, 1), (4, 2)])
+def test_fenrir_solve_mv_square_root(ra, p, n_bobs):
+    """fenrir.solve_mv with kalman_type="square-root" (fenrir.py:421-426, square_root.py:209-219 in the smoothing sweep) against
+    the oracle: means, and the factors as L L^T.  interrogate_rodeo: with an exact measurement the backward filter's predicted
+    factor is singular and square_root.py:172-174 divides by its zero diagonal -- in the reference as in the oracle
+    (tests/test_oracle_fenrir.py)."""
+    from oracle import fenrir as ofen
+    N, t_max, B = 40, 2.0, 3
+    rng = np.random.default_rng(60 + p)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0 = init(np.array([-1., 1.]) + 0.05 * rng.standard_normal((B, 2)), 0.0, theta=theta)
+    Q, R = ra.ibm_init(t_max / N, p, np.array([.1, .1]))
+    Rh = np.linalg.cholesky(R)
+    obs_times = np.array([0.0, 0.5, 1.25, 2.0])
+    n_obs = len(obs_times)
+    y = rng.standard_normal((n_obs, 2, n_bobs))
+    Dw = 0.3 * rng.standard_normal((n_obs, 2, n_bobs, p)); Dw[..., 0, 0] = 1.0
+    Oh = np.tile(np.linalg.cholesky(0.05 * np.eye(n_bobs) + 0.01), (n_obs, 2, 1, 1))
+    from rodeo_amd.inference.fenrir import solve_mv as fenrir_solve_mv
+    m, L = fenrir_solve_mv(None, ra.ode.fitzhugh_nagumo, W, x0, 0.0, t_max, N, ra.interrogate.interrogate_rodeo, (Q, Rh), y,
+                           obs_times, Dw, Oh, kalman_type="square-root", theta=theta)
+    assert m.shape == (B, N + 1, 2, p) and L.shape == (B, N + 1, 2, p, p)
+    for b in range(B):
+        mo, Lo = ofen.solve_mv(None, odes.fitzhugh_nagumo, W, x0[b], 0.0, t_max, N, oi.interrogate_rodeo, (Q, Rh), y, obs_times,
+                               Dw, Oh, kalman_type="square-root", theta=theta[b])
+        scale = np.maximum(np.max(np.abs(mo), axis=(0, 1)), 1.0)
+        assert np.max(np.abs(m[b] - mo) / scale) < 1e-7
+        vo, v = Lo @ np.swapaxes(Lo, -1, -2), L[b] @ np.swapaxes(L[b], -1, -2)
+        dv = np.sqrt(np.abs(np.einsum("nkii->nki", vo)).max(axis=(0, 1)))
+        assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :])) < 1e-6

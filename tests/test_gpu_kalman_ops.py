@@ -113,7 +113,7 @@ def test_broadcast_and_kwargs(ktv):
 def test_errors(ktv, sq):
     from rodeo_amd._lib import RodeoKalmanError
     with pytest.raises(RodeoKalmanError):
-        ktv.predict(np.zeros(20), np.eye(20), np.zeros(20), np.eye(20), np.eye(20))      # n_state > 16 unsupported here
+        ktv.predict(np.zeros(800), np.eye(800), np.zeros(800), np.eye(800), np.eye(800))      # beyond the dense blocks' 768
     with pytest.raises(TypeError):
         sq.smooth_mv(np.zeros(2), np.eye(2), np.zeros(2), np.eye(2), np.zeros(2), np.eye(2), np.eye(2))  # var_state required
 
@@ -198,3 +198,73 @@ def test_standalone_interrogations_builtin_rhs(name, rhs):
         assert [x.shape for x in one] == [(d, 1, p), (d, 1), (d, 1, 1)]
         for x, y in zip(one, got):
             np.testing.assert_array_equal(x, y[0])
+
+
+# ---- blocks beyond the lane-per-item kernels (n_state > 16): one workgroup per item on the dense building blocks ----------
+@pytest.mark.parametrize("p,m", [(20, 3), (48, 16), (160, 32), (176, 8)])
+def test_standard_large_blocks_vs_oracle(ktv, p, m):
+    """The operators are size-agnostic in the reference (standard.py:31-60); at n_state > 16 they run on the dense solver's
+    GEMM / pivoted LU blocks (solve_dense_ops.hpp), e.g. BASELINE config 5's 160 x 160 state with 32 measurements."""
+    rng = np.random.default_rng(p + m)
+    r = _rand_batch(rng, 3, p, m)
+    r["Q"] = r["Q"] / np.sqrt(p)                                              # keep |Q| ~ 1 at any size
+    mp, vp = ktv.predict(r["mu"], r["S"], r["c"], r["Q"], r["R"])
+    omp, ovp = oktv.predict(r["mu"], r["S"], r["c"], r["Q"], r["R"])
+    sv = np.abs(ovp).max()
+    np.testing.assert_allclose(mp, omp, rtol=1e-11, atol=1e-11); np.testing.assert_allclose(vp, ovp, rtol=0, atol=1e-12 * sv)
+    mf, vf = ktv.update(omp, ovp, r["x"], r["a"], r["W"], r["V"])
+    omf, ovf = oktv.update(omp, ovp, r["x"], r["a"], r["W"], r["V"])
+    np.testing.assert_allclose(mf, omf, rtol=0, atol=1e-9 * max(1.0, np.abs(omf).max()))
+    np.testing.assert_allclose(vf, ovf, rtol=0, atol=1e-9 * sv)
+    out = ktv.filter(r["mu"], r["S"], r["c"], r["Q"], r["R"], r["x"], r["a"], r["W"], r["V"])
+    for g, o in zip(out, (omp, ovp, omf, ovf)):
+        np.testing.assert_allclose(g, o, rtol=0, atol=1e-9 * max(1.0, np.abs(o).max()))
+    fo = ktv.forecast(omp, ovp, r["a"], r["W"], r["V"])
+    ofo = oktv.forecast(omp, ovp, r["a"], r["W"], r["V"])
+    np.testing.assert_allclose(fo[0], ofo[0], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(fo[1], ofo[1], rtol=0, atol=1e-11 * np.abs(ofo[1]).max())
+    sm = ktv.smooth(r["xn"], r["mn"], r["Sn"], omf, ovf, omp, ovp, r["Q"])
+    osm = oktv.smooth(r["xn"], r["mn"], r["Sn"], omf, ovf, omp, ovp, r["Q"])
+    for g, o in zip(sm, osm):
+        np.testing.assert_allclose(g, o, rtol=0, atol=1e-8 * max(1.0, np.abs(o).max()))
+    m2 = ktv.smooth_mv(r["mn"], r["Sn"], omf, ovf, omp, ovp, r["Q"])
+    np.testing.assert_allclose(m2[0], osm[2], rtol=0, atol=1e-8 * max(1.0, np.abs(osm[2]).max()))
+    m3 = ktv.smooth_sim(r["xn"], omf, ovf, omp, ovp, r["Q"])
+    np.testing.assert_allclose(m3[1], osm[1], rtol=0, atol=1e-8 * max(1.0, np.abs(osm[1]).max()))
+    sc = ktv.smooth_cond(omf, ovf, omp, ovp, r["Q"])
+    osc = oktv.smooth_cond(omf, ovf, omp, ovp, r["Q"])
+    for g, o in zip(sc, osc):
+        np.testing.assert_allclose(g, o, rtol=0, atol=1e-8 * max(1.0, np.abs(o).max()))
+
+
+@pytest.mark.parametrize("p,m", [(20, 3), (48, 16), (160, 32)])
+def test_square_root_large_blocks_vs_oracle(sq, p, m):
+    """Square-root operators at n_state > 16 (blocked Householder QR, triangular solves; solve_dense_sqrt.hpp): factors compared
+    as L L^T, forecast as the full variance (square_root.py:343-344)."""
+    rng = np.random.default_rng(100 + p + m)
+    r = _rand_batch(rng, 2, p, m)
+    r["Q"] = r["Q"] / np.sqrt(p)
+    LS, LR, LV, LSn = _chol(r["S"]), _chol(r["R"]), _chol(r["V"]), _chol(r["Sn"])
+    def close_f(L, Lo, tol):
+        vo = _sqr(Lo)
+        np.testing.assert_allclose(_sqr(L), vo, rtol=0, atol=tol * np.abs(vo).max())
+    mp, Lp = sq.predict(r["mu"], LS, r["c"], r["Q"], LR)
+    omp, oLp = osq.predict(r["mu"], LS, r["c"], r["Q"], LR)
+    np.testing.assert_allclose(mp, omp, rtol=1e-11, atol=1e-11); close_f(Lp, oLp, 1e-11)
+    assert np.all(np.triu(Lp, 1) == 0.0)
+    mf, Lf = sq.update(omp, oLp, r["x"], r["a"], r["W"], LV)
+    omf, oLf = osq.update(omp, oLp, r["x"], r["a"], r["W"], LV)
+    np.testing.assert_allclose(mf, omf, rtol=0, atol=1e-9 * max(1.0, np.abs(omf).max())); close_f(Lf, oLf, 1e-9)
+    fo = sq.forecast(omp, oLp, r["a"], r["W"], LV)
+    ofo = osq.forecast(omp, oLp, r["a"], r["W"], LV)
+    np.testing.assert_allclose(fo[0], ofo[0], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(fo[1], ofo[1], rtol=0, atol=1e-10 * np.abs(ofo[1]).max())
+    sm = sq.smooth(r["xn"], r["mn"], LSn, omf, oLf, omp, oLp, r["Q"], LR)
+    osm = osq.smooth(r["xn"], r["mn"], LSn, omf, oLf, omp, oLp, r["Q"], LR)
+    for k in (0, 2):
+        np.testing.assert_allclose(sm[k], osm[k], rtol=0, atol=1e-8 * max(1.0, np.abs(osm[k]).max()))
+    close_f(sm[1], osm[1], 1e-8); close_f(sm[3], osm[3], 1e-8)
+    A, bb, C = sq.smooth_cond(omf, oLf, omp, oLp, r["Q"], LR)
+    oA, obb, oC = osq.smooth_cond(omf, oLf, omp, oLp, r["Q"], LR)
+    np.testing.assert_allclose(A, oA, rtol=0, atol=1e-8 * max(1.0, np.abs(oA).max()))
+    np.testing.assert_allclose(bb, obb, rtol=0, atol=1e-8 * max(1.0, np.abs(obb).max())); close_f(C, oC, 1e-8)

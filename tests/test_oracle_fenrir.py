@@ -163,3 +163,71 @@ def test_fenrir_vector_observations_equal_exact_gaussian_loglik():
         Hy[2 * m:2 * m + 2, (n - 1) * p:n * p] = D2
     ref = multivariate_normal.logpdf(y.reshape(-1), Hy @ mu_c, Hy @ S_c @ Hy.T + block_diag(Om2, Om2, Om2), allow_singular=True)
     assert abs(val - ref) < 1e-8 * max(1.0, abs(ref)), (val, ref)
+
+
+def _sqrt_problem(n_bobs):
+    N, t_min, t_max, p = 10, 0.0, 1.0, 3
+    W = np.array([[[0.0, 0.0, 1.0]]])
+    x0 = np.array([[-1.0, 0.0, 1.0]])
+    Q, R = priors.ibm_init((t_max - t_min) / N, p, np.array([0.5]))
+    obs_times = np.array([0.2, 0.5, 1.0])
+    rng = np.random.default_rng(n_bobs)
+    if n_bobs == 1:
+        y = rng.standard_normal((3, 1, 1)) * 0.3 - 0.5
+        D = np.array([[1.0, 0.0, 0.0]])
+        Om = np.array([[0.05]])
+    else:
+        y = rng.standard_normal((3, 1, 2)) * 0.3
+        D = np.array([[1.0, 0.0, 0.0], [0.3, 1.0, 0.0]])
+        Om = np.array([[0.05, 0.01], [0.01, 0.2]])
+    obs_weight = np.tile(D[None, None], (3, 1, 1, 1))
+    obs_var = np.tile(Om[None, None], (3, 1, 1, 1))
+    return dict(N=N, t_min=t_min, t_max=t_max, W=W, x0=x0, Q=Q, R=R, obs_times=obs_times, y=y, obs_weight=obs_weight,
+                obs_var=obs_var, obs_fac=np.linalg.cholesky(obs_var), Rh=np.linalg.cholesky(R))
+
+
+@pytest.mark.parametrize("n_bobs", [1, 2])
+def test_fenrir_square_root_equals_the_standard_value(n_bobs):
+    """kalman_type = "square-root" (fenrir.py:292-296 with square_root.py's forecast, which squares its factor before it is
+    handed to the log-density, square_root.py:343-344): with L L^T inputs (prior_pars[1] = chol R, obs_var = chol Omega) the
+    value is the same log-likelihood -- already pinned to the exact Gaussian value above for the standard form."""
+    s = _sqrt_problem(n_bobs)
+    args = (None, odes.higher_order, s["W"], s["x0"], s["t_min"], s["t_max"], s["N"], oi.interrogate_kramer)
+    std = ofen.fenrir(*args, (s["Q"], s["R"]), s["y"], s["obs_times"], s["obs_weight"], s["obs_var"])
+    sq = ofen.fenrir(*args, (s["Q"], s["Rh"]), s["y"], s["obs_times"], s["obs_weight"], s["obs_fac"], kalman_type="square-root")
+    assert abs(sq - std) < 1e-8 * max(1.0, abs(std)), (sq, std)
+    with pytest.raises(NotImplementedError):
+        ofen.fenrir(*args, (s["Q"], s["R"]), s["y"], s["obs_times"], s["obs_weight"], s["obs_var"], kalman_type="other")
+
+
+def _fixed_noise_interrogation(sd):
+    """Schober's interrogation with a constant measurement noise: var_meas = sd^2 I in covariance form, sd I as the factor in
+    square-root form -- the SAME model in both forms (interrogate_rodeo is not: in square-root mode the reference hands
+    W L- W^T to the update as if it were a factor, interrogate.py:110-113, which changes the model)."""
+    def make(factor):
+        def itg(key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, **params):
+            wgt, mean_meas, var_meas = oi.interrogate_schober(key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, **params)
+            m = var_meas.shape[-1]
+            return wgt, mean_meas, var_meas + (sd if factor else sd * sd) * np.eye(m)
+        return itg
+    return make(False), make(True)
+
+
+def test_fenrir_solve_mv_square_root_equals_the_standard_form():
+    """fenrir.solve_mv and fenrir in square-root form (fenrir.py:421-426, 292-296) against the standard form, which is pinned
+    to the exact Gaussian posterior above.  With an EXACT measurement (kramer, var_meas = 0) the backward filter's predicted
+    covariance is rank deficient, its factor singular, and square_root.py:172-174's triangular solve with it diverges (1e14 in
+    this restatement, as it must in the reference; the covariance form's LU happens to survive) -- so the comparison uses a
+    measurement noise that is the same model in both forms; means and L L^T to 1e-8."""
+    s = _sqrt_problem(1)
+    N = s["N"]
+    itg_std, itg_sqrt = _fixed_noise_interrogation(0.03)
+    args = (None, odes.higher_order, s["W"], s["x0"], s["t_min"], s["t_max"], N)
+    m, L = ofen.solve_mv(*args, itg_sqrt, (s["Q"], s["Rh"]), s["y"], s["obs_times"], s["obs_weight"], s["obs_fac"],
+                         kalman_type="square-root")
+    m2, v2 = ofen.solve_mv(*args, itg_std, (s["Q"], s["R"]), s["y"], s["obs_times"], s["obs_weight"], s["obs_var"])
+    v = L @ np.swapaxes(L, -1, -2)
+    assert np.max(np.abs(m - m2)) < 1e-8 and np.max(np.abs(v - v2)) < 1e-8
+    ll = ofen.fenrir(*args, itg_sqrt, (s["Q"], s["Rh"]), s["y"], s["obs_times"], s["obs_weight"], s["obs_fac"], kalman_type="square-root")
+    ll2 = ofen.fenrir(*args, itg_std, (s["Q"], s["R"]), s["y"], s["obs_times"], s["obs_weight"], s["obs_var"])
+    assert abs(ll - ll2) < 1e-8 * max(1.0, abs(ll2))
