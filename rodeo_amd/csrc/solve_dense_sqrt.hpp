@@ -104,23 +104,29 @@ __device__ __forceinline__ double slab_sum(double x) {                // x(l) + 
 // SIMD each step took the sum of both instruction streams -- 8 waves x 15 rows per lane ran 1.6x slower than 4 x 30); the
 // other four only take part in the barriers.
 constexpr int QR_PW = 4;                                // panel waves
+// acc += x(lane J of this lane's 16-lane row) * y: the broadcast rides on the FMA itself (gfx90a+: 64-bit DPP exists for
+// row_newbcast only) -- no separate move per entry of the pivot column.  Inline assembly: hipcc has no builtin for it.
+template <int J>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double x, double y) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+}
+
 template <int RT, int J>
 __device__ __forceinline__ void qr_panel_col(double (&tr)[16], double (&ta)[RT], double& myscale, bool act, int c, int wave,
                                              int lane, int pg_off, int tau_off) {
-    double pt[16], pu[RT];
     double gt = 0.0;
     double* const bb = g_lds + pg_off + (J & 1) * (16 * QR_PW);      // [c][wave]: partial dots of the rows below the triangle
     if (act) {
+        // dot products of the pivot column (lane J of every row: its triangle entries are the same in all rows, its tall
+        // entries those of this lane's slab) with this lane's column
+        double g4[4] = {0.0, 0.0, 0.0, 0.0}, t2[2] = {0.0, 0.0};      // independent accumulators: no back-to-back dependence
+        asm volatile("s_nop 1");                                      // (VALU write -> DPP read of the same register: 2 wait states)
 #pragma unroll
-        for (int i = J; i < 16; ++i) pt[i] = readlane_f64(tr[i], J);
+        for (int i = 0; i < RT; ++i) fmac_rowbcast<J>(g4[i & 3], ta[i], ta[i]);
 #pragma unroll
-        for (int i = 0; i < RT; ++i) pu[i] = row_bcast_f64<J>(ta[i]);
-        double gu = 0.0;
-#pragma unroll
-        for (int i = J + 1; i < 16; ++i) gt = fma(pt[i], tr[i], gt);
-#pragma unroll
-        for (int i = 0; i < RT; ++i) gu = fma(pu[i], ta[i], gu);
-        gu = slab_sum(gu);
+        for (int i = J + 1; i < 16; ++i) fmac_rowbcast<J>(t2[i & 1], tr[i], tr[i]);
+        gt = t2[0] + t2[1];
+        double gu = slab_sum((g4[0] + g4[1]) + (g4[2] + g4[3]));
         if (lane < 16) bb[c * QR_PW + wave] = gu;
     }
     __syncthreads();
@@ -130,22 +136,24 @@ __device__ __forceinline__ void qr_panel_col(double (&tr)[16], double (&ta)[RT],
         for (int w = 0; w < QR_PW; ++w) { G += bb[c * QR_PW + w]; Nn += bb[J * QR_PW + w]; }
         // LAPACK dlarfg: beta = -sign(alpha) ||(alpha, x)||, tau = (beta - alpha) / beta, v = x / (alpha - beta), v_J = 1
         // (||x||^2 = the pivot column's dot product with itself: lane J's triangle part, column J's exchanged sums)
-        const double alpha = pt[J], xn2 = readlane_f64(gt, J) + Nn;
+        const double alpha = readlane_f64(tr[J], J), xn2 = readlane_f64(gt, J) + Nn;
         const bool refl = xn2 != 0.0;
         const double beta = refl ? -copysign(sqrt(fma(alpha, alpha, xn2)), alpha) : alpha;
         const double tau = refl ? (beta - alpha) * fast_rcp(beta) : 0.0;
         const double scale = refl ? fast_rcp(alpha - beta) : 0.0;
         if (threadIdx.x == 0) g_lds[tau_off + J] = tau;
-        // w_c = tau (a_Jc + v_below . a_c) for the columns right of J;  a_c <- a_c - v w_c with v = x scale
+        // w_c = tau (a_Jc + v_below . a_c) for the columns right of J;  a_c <- a_c - v w_c with v = x scale.  The pivot lane
+        // (and the columns left of it) run with w_c = 0: untouched.
         const bool right = c > J, piv = c == J;
         const double wc = right ? tau * fma(scale, gt + G, tr[J]) : 0.0;
         myscale = piv ? scale : myscale;
         tr[J] = piv ? beta : tr[J] - wc;
         const double z = -(scale * wc);
+        asm volatile("s_nop 1");
 #pragma unroll
-        for (int i = J + 1; i < 16; ++i) tr[i] = fma(pt[i], z, tr[i]);
+        for (int i = J + 1; i < 16; ++i) fmac_rowbcast<J>(tr[i], tr[i], z);
 #pragma unroll
-        for (int i = 0; i < RT; ++i) ta[i] = fma(pu[i], z, ta[i]);
+        for (int i = 0; i < RT; ++i) fmac_rowbcast<J>(ta[i], ta[i], z);
     }
 }
 template <int RT, int J>

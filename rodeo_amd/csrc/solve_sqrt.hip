@@ -135,8 +135,10 @@ static int launch_fwd_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& 
         case 4: return launch_fwd_sqrt_p<RHS, 4>(h, a, c->interrogate);
         case 5: return launch_fwd_sqrt_p<RHS, 5>(h, a, c->interrogate);
         case 6: return launch_fwd_sqrt_p<RHS, 6>(h, a, c->interrogate);
+        case 7: return launch_fwd_sqrt_p<RHS, 7>(h, a, c->interrogate);
+        case 8: return launch_fwd_sqrt_p<RHS, 8>(h, a, c->interrogate);
     }
-    set_error("square-root solver supports n_bstate in [2, 6], got %d", c->n_bstate);
+    set_error("square-root solver supports n_bstate in [2, 8], got %d", c->n_bstate);
     return RK_ERR_UNSUPPORTED;
 }
 
@@ -144,7 +146,7 @@ bool is_user_rhs(int rhs_id);
 int user_forward_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a);
 
 int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode) {
-    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6, RK_ERR_UNSUPPORTED, "square-root solver supports n_bstate in [2, 6], got %d",
+    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 8, RK_ERR_UNSUPPORTED, "square-root solver supports n_bstate in [2, 8], got %d",
                c->n_bstate);
     int rc;
     if (is_user_rhs(c->rhs_id)) rc = user_forward_sqrt(h, c, a);      // hiprtc build of fwd_sqrt_kernel (rhs_jit.hip)
@@ -162,7 +164,7 @@ int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode)
         if (mode == RK_MODE_SIM) hipLaunchKernelGGL((bwd_sqrt_kernel<P_, true>), grid, block, 0, h->stream, a);  \
         else hipLaunchKernelGGL((bwd_sqrt_kernel<P_, false>), grid, block, 0, h->stream, a);             \
         break;
-    switch (c->n_bstate) { RK_SQ(2) RK_SQ(3) RK_SQ(4) RK_SQ(5) RK_SQ(6) }
+    switch (c->n_bstate) { RK_SQ(2) RK_SQ(3) RK_SQ(4) RK_SQ(5) RK_SQ(6) RK_SQ(7) RK_SQ(8) }
 #undef RK_SQ
     t.stop();
     RK_HIP(hipGetLastError());

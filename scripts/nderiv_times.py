@@ -48,3 +48,20 @@ for p in [int(v) for v in sys.argv[1:]] or [3, 4, 5, 6, 7, 8]:
         print(json.dumps({"config": f"FN n_deriv={p}, B=1024, N=800, solve_sim+chkrebtii", "layout": plan.layout,
                           "kernels_ms": k, "total_ms": round(sum(k.values()), 4)}), flush=True)
         del plan
+
+
+# kalman_type = "square-root" on the same shape (lane-per-trajectory kernels, solve_sqrt.hip): what the factor form costs
+# next to the covariance form's MFMA tiles
+for p in [int(v) for v in sys.argv[1:] if int(v) <= 6] or [3, 4, 5]:
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0 = init(x0v, 0.0, theta=theta)
+    N = 4000
+    Q, R = ra.ibm_init(40.0 / N, p, np.array([0.1, 0.1]))
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, x0, 0.0, 40.0, N, ra.interrogate.interrogate_kramer,
+                        (Q, np.linalg.cholesky(R)), kalman_type="square-root", theta=theta)
+    k = timed(plan, lambda: plan.mv(None), reps=3)
+    tot = sum(k.values())
+    print(json.dumps({"config": f"FN n_deriv={p}, B=1024, N=4000, solve_mv+kramer, kalman_type=square-root", "layout": plan.layout,
+                      "kernels_ms": k, "total_ms": round(tot, 4), "traj_steps_per_s": B * N / (tot * 1e-3),
+                      "hbm_frac_algorithmic": 3 * 2 * p * (p + 1) * 8 * B * N / (tot * 1e-3) / 8e12}), flush=True)
+    del plan

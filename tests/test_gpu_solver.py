@@ -559,19 +559,27 @@ def test_two_state_blocks_run_on_the_three_state_tiles(ra, name):
     assert x.shape == (B, 121, 2, 2) and np.max(np.abs(x - xo)) < 1e-7
 
 
-@pytest.mark.parametrize("p", [3, 5, 6])
+@pytest.mark.parametrize("p", [3, 5, 6, 7, 8])
 def test_square_root_solver_traced_python_rhs_and_higher_n_deriv(ra, p):
     """kalman_type='square-root' with an ordinary Python ode_fun (traced, compiled by hiprtc: the forward square-root
     kernel is a template over the right-hand side like the standard one) and at n_deriv = 5, 6 -- where the square-root
-    form is what a user reaches for (src/rodeo/kalmantv/square_root.py; the covariance form loses definiteness first)."""
+    form is what a user reaches for (src/rodeo/kalmantv/square_root.py; the covariance form loses definiteness first), up to
+    n_deriv = 8 (the blocked-tile covariance kernels' range; the square-root lane kernels spill there: a functional path)."""
     def fitz(X, t, theta):
         a, b, c = theta
         V, R = X[0, 0], X[1, 0]
         return np.array([[c * (V - V * V * V / 3 + R)], [-1 / c * (V - a + b * R)]])
-    B, N = 4, 50
-    s = fitz_problem(ra, N=N, t_max=1.0, sigma=.1, B=B, seed=p, p=p)
-    pr = _chol_prior(s["prior"])
-    args = (s["W"], s["x0"], 0.0, 1.0, N)
+    B, N, t_max = 4, 50, 1.0
+    s = fitz_problem(ra, N=N, t_max=t_max, sigma=.1, B=B, seed=p, p=p)
+    if p <= 6:
+        pr = _chol_prior(s["prior"])
+    else:
+        # n_deriv = 7, 8: the IBM variance matrix is singular in fp64 whatever the step (cond 2e21 / 9e24: a Hilbert-type
+        # matrix), so its numerical Cholesky factor -- the INPUT of this mode -- is meaningless.  The kernels' sizes are
+        # exercised with the IBM weight matrix and a well-conditioned lower factor in its place.
+        rng = np.random.default_rng(p)
+        pr = (s["prior"][0], 0.05 * (np.eye(p) + 0.2 * np.tril(rng.standard_normal((2, p, p)), -1)))
+    args = (s["W"], s["x0"], 0.0, t_max, N)
     for name in ("kramer", "rodeo"):
         g, o = _itg(ra, name)
         mo, Lo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, o, pr, kalman_type="square-root", theta=s["theta"])
@@ -579,8 +587,8 @@ def test_square_root_solver_traced_python_rhs_and_higher_n_deriv(ra, p):
         for fun in (fitz, ra.ode.fitzhugh_nagumo):
             m, L = ra.solve_mv(None, fun, *args, g, pr, kalman_type="square-root", theta=s["theta"])
             assert m.shape == (B, N + 1, 2, p) and L.shape == (B, N + 1, 2, p, p)
-            assert np.max(np.abs(m - mo) / scale) < 1e-8
-            _vclose(_sq(L), _sq(Lo), 1e-6)
+            assert np.max(np.abs(m - mo) / scale) < (1e-8 if p <= 6 else 1e-7)
+            _vclose(_sq(L), _sq(Lo), 1e-6 if p <= 6 else 1e-5)
     x = ra.solve_sim(3, fitz, *args, ra.interrogate.interrogate_rodeo, pr, kalman_type="square-root", theta=s["theta"])
     xo = scan.solve_sim(3, odes.fitzhugh_nagumo, *args, oi.interrogate_rodeo, pr, kalman_type="square-root", theta=s["theta"])
     assert np.max(np.abs(x - xo) / np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1.0)) < 1e-6

@@ -46,12 +46,115 @@ def _fitz(ra, p, B=None, seed=0, N=50, t_max=0.5, sigma=0.1):
     return dict(W=W, x0=x0, theta=theta, prior=ra.ibm_init(t_max / N, p, np.array([sigma] * 2)), N=N, t_max=t_max)
 
 
-def _close(m, mo, v, vo, p):
+def _close(m, mo, v, vo, p, R=None, entrywise=True, yard=None):
+    """Means relative to the scale of each derivative order.  Variances TWICE: against the largest variance (dominated by the
+    highest derivatives) and ENTRY BY ENTRY against sd_i sd_j of the two components involved (sd = the component's largest
+    posterior standard deviation over the run) -- so that an error in Sigma_00 or Sigma_01, the entries a user reads, is
+    measured on their own scale and cannot hide under the high-derivative variances."""
     scale = np.maximum(np.max(np.abs(mo), axis=tuple(range(mo.ndim - 1))), 1.0)        # per derivative order
     em = np.max(np.abs(m - mo) / scale)
     ev = np.max(np.abs(v - vo)) / np.max(np.abs(vo))
-    assert em < TOL_MEAN[p] and ev < TOL_VAR[p], (p, em, ev)
+    sd = np.sqrt(np.abs(np.einsum("...ii->...i", vo)).max(axis=tuple(range(vo.ndim - 2))))
+    if R is not None:       # a component pinned by an exact measurement (schober: the measured derivative) has variance 0 + rounding
+        sd = np.maximum(sd, 1e-4 * np.sqrt(np.einsum("...ii->...i", np.asarray(R)).max(axis=tuple(range(np.ndim(R) - 2)))))
+    ee = np.max(np.abs(v - vo) / (sd[:, None] * sd[None, :]))
+    assert em < TOL_MEAN[p] and ev < TOL_VAR[p], (p, em, ev, ee)
+    if entrywise and not ee < 10 * TOL_VAR[p]:
+        # beyond the entry-wise bound: legitimate only if the fp64 ORACLE is as far from extended precision (conditioning)
+        assert yard is not None, (p, em, ev, ee)
+        ml, vl = yard()
+        e_dev, e_orc = np.max(np.abs(v - vl) / (sd[:, None] * sd[None, :])), np.max(np.abs(vo - vl) / (sd[:, None] * sd[None, :]))
+        assert e_dev <= 20 * e_orc + 1e-12, (p, ee, float(e_dev), float(e_orc))
     return em, ev
+
+
+def _longdouble_solve_mv(s, name):
+    """solve_mv of the FitzHugh-Nagumo problem `s` restated in np.longdouble (x87 extended precision: 64-bit mantissa): the
+    recursion of src/rodeo/solve.py:47-122, 257-301 with standard.py:57-59, 93-102, 175-176, 210-216 and an LU with partial
+    pivoting for standard.py:176, all in plain loops -- the yardstick that tells conditioning from defects: a correct fp64
+    implementation must sit about as far from it as the fp64 oracle does."""
+    LD = np.longdouble
+    W, x0, th = s["W"].astype(LD), s["x0"].astype(LD), np.asarray(s["theta"], dtype=LD)
+    Q, R = (a.astype(LD) for a in s["prior"])
+    N, t_max = s["N"], s["t_max"]
+    B, d, p = x0.shape
+
+    def lu_solve(A, Bm):
+        A, Bm = A.copy(), Bm.copy()
+        n = A.shape[0]
+        for k in range(n):
+            pk = k + int(np.argmax(np.abs(A[k:, k])))
+            if pk != k:
+                A[[k, pk]] = A[[pk, k]]; Bm[[k, pk]] = Bm[[pk, k]]
+            for i in range(k + 1, n):
+                l = A[i, k] / A[k, k]
+                A[i, k:] -= l * A[k, k:]; Bm[i] -= l * Bm[k]
+        for k in range(n - 1, -1, -1):
+            Bm[k] = (Bm[k] - A[k, k + 1:] @ Bm[k + 1:]) / A[k, k]
+        return Bm
+    ms = np.zeros((B, N + 1, d, p), dtype=LD); vs = np.zeros((B, N + 1, d, p, p), dtype=LD)
+    for b in range(B):
+        a_, b_, c_ = th[b]
+        mu, Sig = x0[b].copy(), np.zeros((d, p, p), dtype=LD)
+        mf = np.zeros((N + 1, d, p), dtype=LD); vf = np.zeros((N + 1, d, p, p), dtype=LD)
+        mp = np.zeros_like(mf); vp = np.zeros_like(vf)
+        mf[0] = mu
+        for n in range(N):
+            mup = np.stack([Q[k] @ mu[k] for k in range(d)])
+            Sp = np.stack([Q[k] @ Sig[k] @ Q[k].T + R[k] for k in range(d)])
+            V_, R_ = mup[0, 0], mup[1, 0]
+            f = np.array([c_ * (V_ - V_ * V_ * V_ / 3 + R_), -(V_ - a_ + b_ * R_) / c_], dtype=LD)
+            J = np.zeros((d, p), dtype=LD)
+            if name == "kramer":
+                J[0, 0] = c_ * (1 - V_ * V_); J[1, 0] = -b_ / c_
+            for k in range(d):
+                Wt = W[k, 0] - J[k]
+                am = -f[k] + J[k] @ mup[k]
+                WS = Wt @ Sp[k]
+                Sm = WS @ Wt + (W[k, 0] @ Sp[k] @ W[k, 0] if name == "rodeo" else LD(0))
+                K = (Sp[k] @ Wt) / Sm
+                mu[k] = mup[k] + K * (LD(0) - (Wt @ mup[k] + am))
+                Sig[k] = Sp[k] - np.outer(K, WS)
+            mf[n + 1], vf[n + 1], mp[n + 1], vp[n + 1] = mu, Sig, mup, Sp
+        ms[b, N], vs[b, N] = mf[N], vf[N]
+        cm, cv = mf[N].copy(), vf[N].copy()
+        for n in range(N - 1, 0, -1):
+            for k in range(d):
+                T = vf[n, k] @ Q[k].T
+                G = lu_solve(vp[n + 1, k], T.T).T
+                cm[k] = mf[n, k] + G @ (cm[k] - mp[n + 1, k])
+                cv[k] = vf[n, k] + G @ (cv[k] - vp[n + 1, k]) @ G.T
+            ms[b, n], vs[b, n] = cm, cv
+        ms[b, 0] = x0[b]
+    return ms, vs
+
+
+@pytest.mark.parametrize("p,name", [(7, "kramer"), (8, "kramer"), (4, "schober"), (5, "schober"), (6, "schober"), (7, "schober"),
+                                    (8, "schober")])
+def test_gap_to_the_oracle_is_conditioning_not_a_defect(ra, p, name):
+    """Where the fp64 bounds are loose -- n_deriv = 7, 8 (1e-6 .. 1e-4), and interrogate_schober at every n_deriv, whose exact
+    measurement of x' leaves the smoother with singular filtered covariances (entry-wise errors of 1e-7 .. 1e-5 on the LOW
+    derivatives' own scale, invisible next to the largest variance) -- the yardstick is an extended-precision restatement of
+    the same recursion: the DEVICE is about as far from it as the fp64 ORACLE is (within a factor 20 plus a floor at rounding
+    level), entry by entry on each entry's own scale.  What separates device and oracle is the problem's conditioning, not the
+    blocked-tile arithmetic (bmm_tn, the rows chain)."""
+    s = _fitz(ra, p, B=2, seed=p) if p >= 7 else _fitz(ra, p, B=2, seed=p, N=60, t_max=1.2)
+    args = (s["W"], s["x0"], 0.0, s["t_max"], s["N"])
+    g, o = _itg(ra, name)
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
+    plan.mv(None)
+    m, v = plan.state_host()
+    mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
+    ml, vl = _longdouble_solve_mv(s, name)
+    scale = np.maximum(np.max(np.abs(mo), axis=(0, 1, 2)), 1.0)
+    sd = np.sqrt(np.abs(np.einsum("...ii->...i", vo)).max(axis=(0, 1, 2)))
+    sd = np.maximum(sd, 1e-4 * np.sqrt(np.einsum("...ii->...i", s["prior"][1]).max(axis=0)))     # (pinned components)
+    sv = sd[:, None] * sd[None, :]
+    e_dev_m = float(np.max(np.abs(m - ml) / scale)); e_orc_m = float(np.max(np.abs(mo - ml) / scale))
+    e_dev_v = float(np.max(np.abs(v - vl) / sv)); e_orc_v = float(np.max(np.abs(vo - vl) / sv))
+    print(f"\nn_deriv = {p}, {name}: means  device-ld {e_dev_m:.2e}  oracle-ld {e_orc_m:.2e};  variances (per entry)  device-ld "
+          f"{e_dev_v:.2e}  oracle-ld {e_orc_v:.2e}")
+    assert e_dev_m <= 20 * e_orc_m + 1e-12 and e_dev_v <= 20 * e_orc_v + 1e-12, (e_dev_m, e_orc_m, e_dev_v, e_orc_v)
 
 
 def _plan_layout(ra, p):
@@ -72,7 +175,8 @@ def test_blocked_tiles_solve_mv_fitzhugh(ra, p, name):
         assert plan.layout == _plan_layout(ra, p)
     mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
     assert m.shape == (5, s["N"] + 1, 2, p) and v.shape == (5, s["N"] + 1, 2, p, p)
-    _close(m, mo, v, vo, p)
+    # (schober's entry-wise errors are conditioning: test_gap_to_the_oracle_is_conditioning_not_a_defect holds its yardstick)
+    _close(m, mo, v, vo, p, s["prior"][1], entrywise=name != "schober")
     np.testing.assert_array_equal(m[:, 0], s["x0"])
     assert np.all(v[:, 0] == 0)
 
@@ -145,7 +249,7 @@ def test_blocked_tiles_other_block_counts(ra, p, rhs):
         g, o = _itg(ra, name)
         m, v = ra.solve_mv(None, fun, W, x0, 0.0, t_max, N, g, prior, **kw)
         mo, vo = scan.solve_mv(None, ofun, W, x0, 0.0, t_max, N, o, prior, **kw)
-        _close(m, mo, v, vo, p)
+        _close(m, mo, v, vo, p, prior[1])
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 9, 10, 16, 17, 25, 26, 33])
@@ -157,7 +261,7 @@ def test_blocked_tiles_short_horizons_and_ragged_batches(ra, N, B, p):
     args = (s["W"], s["x0"], 0.0, s["t_max"], N)
     m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, s["prior"], theta=s["theta"])
     mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, s["prior"], theta=s["theta"])
-    _close(m, mo, v, vo, p)
+    _close(m, mo, v, vo, p, s["prior"][1], yard=lambda: _longdouble_solve_mv(s, "kramer"))
     x = ra.solve_sim(5, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_rodeo, s["prior"], theta=s["theta"])
     xo = scan.solve_sim(5, odes.fitzhugh_nagumo, *args, oi.interrogate_rodeo, s["prior"], theta=s["theta"])
     assert x.shape == xo.shape
@@ -197,11 +301,11 @@ def test_blocked_tiles_filter_and_mv_with_chkrebtii(ra, p):
     plan.filter(9)
     mf, vf = plan.state_host()
     ref = scan.solve_filter(9, odes.fitzhugh_nagumo, *args, o, *s["prior"], theta=s["theta"])
-    _close(mf, ref["state_filt"][0], vf, ref["state_filt"][1], p)
+    _close(mf, ref["state_filt"][0], vf, ref["state_filt"][1], p, s["prior"][1])
     plan.mv(9)
     m, v = plan.state_host()
     mo, vo = scan.solve_mv(9, odes.fitzhugh_nagumo, *args, o, s["prior"], theta=s["theta"])
-    _close(m, mo, v, vo, p)
+    _close(m, mo, v, vo, p, s["prior"][1])
 
 
 def test_blocked_tiles_basic_and_logposterior_read_the_tile_layout(ra):
@@ -247,7 +351,7 @@ def test_blocked_tiles_traced_python_rhs(ra):
         assert plan.layout == _lib.LAYOUT_TILEP
         m, v = plan.state_host()
         mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, s["prior"], theta=s["theta"])
-        _close(m, mo, v, vo, p)
+        _close(m, mo, v, vo, p, s["prior"][1])
     # six variables (the user ODE of test_gpu_user_rhs.py, Jacobian by duals) at n_deriv = 5
     from test_gpu_user_rhs import SIX_SRC, _six_host
     six = ra.ode.from_source("AutoJac<Six>", SIX_SRC, 6, (("theta", 4),), _six_host, name="six_p5")
@@ -275,4 +379,4 @@ def test_blocked_tiles_traced_python_rhs(ra):
     assert plan.layout == _lib.LAYOUT_TILEP
     m, v = plan.state_host()
     mo, vo = scan.solve_mv(None, o_ode, W, x0, 0., 0.8, N, oi.interrogate_kramer, prior, theta=theta)
-    _close(m, mo, v, vo, p)
+    _close(m, mo, v, vo, p, prior[1])
