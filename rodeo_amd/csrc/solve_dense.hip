@@ -120,6 +120,8 @@ __shared__ double g_qd[BD_MAXP * BD_MAX];         // diagonal blocks of a block-
 
 // ---------------------------------------------------------------------------------------------------------------
 // C (M x N, ldc) = ce * E + cab * op(A) op(B); row-major operands in global memory, the whole workgroup cooperates.
+// (A rectangle-per-wave tile ownership -- 3 A + 5 B fragments from LDS for 15 MFMAs instead of two reads per MFMA -- was built
+// and measured 10-35 % SLOWER in round 3: the tiles' per-MFMA guards cost more than the fragment reads save.)
 // v_mfma_f64_16x16x4_f64 with BOTH operands staged through LDS in k-chunks of 32 (As[k][i], Bs[k][j], row stride 177
 // doubles: the fragment reads and the transposing stores are both at most 2-way on the banks), so a transposed operand
 // only changes how its chunk is staged and there is ONE copy of the inner loop: the kernels issue their products
@@ -140,8 +142,9 @@ struct GemmOp {
     double ce, cab;
     bool ta, tb;
 };
-constexpr int G_KC = 32, G_SP = 177, G_MB = 160;
+constexpr int G_KC = 32, G_SP = 177, G_MB = 160, G_TPW = ((G_MB / 16) * (G_MB / 16) + NWAVE - 1) / NWAVE;
 static_assert(2 * G_KC * G_SP <= LDS_DOUBLES, "GEMM staging exceeds the LDS buffer");
+static_assert((G_MB / 16) * (G_MB / 16) <= G_TPW * NWAVE, "tiles per wave");
 
 // dst[k][j] = src[k * ld + j] for k < kn, j < jn; zero elsewhere in the 32 x 160 chunk  (source rows -> LDS rows)
 __device__ __forceinline__ void stage_rows(double* dst, cgd* src, int ld, int kn, int jn) {
@@ -173,26 +176,13 @@ __device__ __forceinline__ void stage_cols(double* dst, cgd* src, int ld, int kn
     }
 }
 
-// Tile ownership inside a macro-block: the tiles form a (tile rows x tile columns) grid that is cut into gr x gc = 8
-// rectangles, one per wave (gr = 4 row groups when there are at least four tile rows, else as many as there are; the
-// columns take the rest), so that a wave's up to G_RB x G_CB tiles share their fragments: per k-step of 4 it reads G_RB
-// A fragments and G_CB B fragments from LDS for G_RB * G_CB MFMAs (the first version dealt the tiles round-robin and
-// read two fragments per MFMA; its MFMA phase ran at the LDS instruction rate, 45 % of the matrix pipe).  Waves w and
-// w + 4 share a SIMD: the row groups are ordered so that a large and a small one meet there.
-constexpr int G_RB = 3, G_CB = 5;
-__device__ __forceinline__ void gemm_split(int n, int parts, int idx, int& first, int& count) {   // n items in `parts` nearly equal runs
-    const int base = n / parts, rem = n - base * parts;
-    first = idx * base + min(idx, rem);
-    count = base + (idx < rem ? 1 : 0);
-}
-
 __device__ __noinline__ void wg_gemm(const GemmOp& g_) {
     double* const lds = g_lds;
-    const GemmOp& gr_ = *uni(&g_);
+    const GemmOp& gr = *uni(&g_);
     struct { gd* C; cgd *A, *B, *E; int ldc, lda, ldb, lde, M, N, K; double ce, cab; bool ta, tb; } g;
-    g.C = uni_g(gr_.C); g.ldc = uni(gr_.ldc); g.A = uni_g(gr_.A); g.lda = uni(gr_.lda); g.B = uni_g(gr_.B); g.ldb = uni(gr_.ldb);
-    g.M = uni(gr_.M); g.N = uni(gr_.N); g.K = uni(gr_.K); g.E = uni_g(gr_.E); g.lde = uni(gr_.lde);
-    g.ce = uni(gr_.ce); g.cab = uni(gr_.cab); g.ta = uni((int)gr_.ta) != 0; g.tb = uni((int)gr_.tb) != 0;
+    g.C = uni_g(gr.C); g.ldc = uni(gr.ldc); g.A = uni_g(gr.A); g.lda = uni(gr.lda); g.B = uni_g(gr.B); g.ldb = uni(gr.ldb);
+    g.M = uni(gr.M); g.N = uni(gr.N); g.K = uni(gr.K); g.E = uni_g(gr.E); g.lde = uni(gr.lde);
+    g.ce = uni(gr.ce); g.cab = uni(gr.cab); g.ta = uni((int)gr.ta) != 0; g.tb = uni((int)gr.tb) != 0;
     double* const As = lds;
     double* const Bs = lds + G_KC * G_SP;
     const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
@@ -201,19 +191,10 @@ __device__ __noinline__ void wg_gemm(const GemmOp& g_) {
     for (int i0 = 0; i0 < g.M; i0 += G_MB)
         for (int j0 = 0; j0 < g.N; j0 += G_MB) {
             const int mb = min(G_MB, g.M - i0), nbk = min(G_MB, g.N - j0);
-            const int ntr = (mb + 15) >> 4, ntc = (nbk + 15) >> 4;   // tile rows / columns of this macro-block (<= 10 each)
-            // the wave's rectangle of tiles
-            const int gr = ntr >= 4 ? 4 : ntr, gc = NWAVE / gr;      // gr in {1, 2, 3, 4}: gc = 8, 4, 2, 2 (gr = 3 leaves two waves idle)
-            const int wc = wave / gr, wr = (wc & 1) ? gr - 1 - wave % gr : wave % gr;   // (odd column groups take the row groups in reverse)
-            int tr0, trn, tc0, tcn;
-            gemm_split(ntr, gr, wr, tr0, trn);
-            gemm_split(ntc, gc, wc < gc ? wc : 0, tc0, tcn);
-            if (wc >= gc) { trn = 0; tcn = 0; }
-            d4 acc[G_RB][G_CB];
+            const int nt = (nbk + 15) >> 4, T = ((mb + 15) >> 4) * nt;
+            d4 acc[G_TPW];
 #pragma unroll
-            for (int rb = 0; rb < G_RB; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < G_CB; ++cb) acc[rb][cb] = d4{0, 0, 0, 0};
+            for (int q = 0; q < G_TPW; ++q) acc[q] = d4{0, 0, 0, 0};
             for (int k0 = 0; k0 < g.K; k0 += G_KC) {
                 const int kn = min(G_KC, g.K - k0);
                 __syncthreads();                                    // the previous chunk has been consumed
@@ -222,43 +203,38 @@ __device__ __noinline__ void wg_gemm(const GemmOp& g_) {
                 if (g.tb) stage_cols(Bs, g.B + (size_t)j0 * g.ldb + k0, g.ldb, kn, nbk);     // B is N x K
                 else      stage_rows(Bs, g.B + (size_t)k0 * g.ldb + j0, g.ldb, kn, nbk);     // B is K x N
                 __syncthreads();
-                const double* const ap = As + frag + 16 * tr0;
-                const double* const bp = Bs + frag + 16 * tc0;
 #pragma unroll
-                for (int kq = 0; kq < G_KC / 4; ++kq) {
-                    double af[G_RB], bf[G_CB];
+                for (int q = 0; q < G_TPW; ++q) {
+                    const int e = wave + NWAVE * q;
+                    if (e < T) {
+                        const int ti = e / nt, tj = e - ti * nt;
+                        const double* ap = As + frag + 16 * ti;
+                        const double* bp = Bs + frag + 16 * tj;
 #pragma unroll
-                    for (int rb = 0; rb < G_RB; ++rb) af[rb] = ap[4 * kq * G_SP + 16 * (rb < trn ? rb : 0)];
-#pragma unroll
-                    for (int cb = 0; cb < G_CB; ++cb) bf[cb] = bp[4 * kq * G_SP + 16 * (cb < tcn ? cb : 0)];
-#pragma unroll
-                    for (int rb = 0; rb < G_RB; ++rb)
-#pragma unroll
-                        for (int cb = 0; cb < G_CB; ++cb)
-                            if (rb < trn && cb < tcn)
-                                acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[rb], bf[cb], acc[rb][cb], 0, 0, 0);
+                        for (int kq = 0; kq < G_KC / 4; ++kq)
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * kq * G_SP], bp[4 * kq * G_SP], acc[q], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
-            for (int rb = 0; rb < G_RB; ++rb)
+            for (int q = 0; q < G_TPW; ++q) {
+                const int e = wave + NWAVE * q;
+                if (e < T) {
+                    const int ti = e / nt, tj = e - ti * nt;
+                    const int j = j0 + 16 * tj + lo;
+                    double ev[4];
 #pragma unroll
-                for (int cb = 0; cb < G_CB; ++cb) {
-                    if (rb < trn && cb < tcn) {
-                        const int ti = tr0 + rb, tj = tc0 + cb;
-                        const int j = j0 + 16 * tj + lo;
-                        double ev[4];
+                    for (int v = 0; v < 4; ++v) {
+                        const int ii = i0 + 16 * ti + 4 * v + hi;
+                        ev[v] = (g.E && ii < g.M && j < g.N) ? g.E[ii * g.lde + j] : 0.0;
+                    }
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int ii = i0 + 16 * ti + 4 * v + hi;
-                            ev[v] = (g.E && ii < g.M && j < g.N) ? g.E[ii * g.lde + j] : 0.0;
-                        }
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int ii = i0 + 16 * ti + 4 * v + hi;
-                            if (ii < g.M && j < g.N) g.C[ii * g.ldc + j] = fma(g.ce, ev[v], g.cab * acc[rb][cb][v]);
-                        }
+                    for (int v = 0; v < 4; ++v) {
+                        const int ii = i0 + 16 * ti + 4 * v + hi;
+                        if (ii < g.M && j < g.N) g.C[ii * g.ldc + j] = fma(g.ce, ev[v], g.cab * acc[q][v]);
                     }
                 }
+            }
         }
     __syncthreads();
 }
