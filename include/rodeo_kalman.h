@@ -81,7 +81,10 @@ extern "C" {
                                      block: [Sigma row-major (p*p) | mu (p)]; mean_state is not used (may be NULL)
                                      (RK_LAYOUT_TILE4 is this format at p = 4)                                   */
 #define RK_LAYOUT_TRAJ_MAJOR   2  /* dense large-block path: the reference's own layout with a leading batch
-                                     axis, mean_state (B, N+1, d, p), var_state (B, N+1, d, p, p)            */
+                                     axis, mean_state (B, N+1, d, p), var_state (B, N+1, d, p, p).  With
+                                     kalman_type = RK_KALMAN_SQRT var_state (and var_pred) hold the LOWER factors
+                                     L_n row-major, exact zeros above the diagonal (what src/rodeo/solve.py
+                                     returns in that mode)                                                    */
 
 typedef struct rk_handle_s* rk_handle;
 
@@ -184,7 +187,10 @@ int rk_solve_layout(const rk_solve_cfg* cfg, int32_t mode, int32_t* layout);
  * RK_LAYOUT_TILE4 likewise (20 doubles per tile + 128 per wave); always size tile buffers with this function.   */
 int rk_solve_sizes(const rk_solve_cfg* cfg, int32_t layout, size_t* mean_bytes, size_t* var_bytes);
 
-/* bytes of device scratch (rk_solve_out.workspace) the configuration needs; 0 for the small-block kernels */
+/* bytes of device scratch (rk_solve_out.workspace) the configuration needs; 0 for the small-block kernels.  Dense path
+ * with RK_KALMAN_SQRT and mode != RK_MODE_FILTER: per-trajectory scratch PLUS the predicted factors of every step,
+ * (B, N+1, p, p) doubles (src/rodeo/kalmantv/square_root.py:170-175 solves with them in the backward pass), unless
+ * RK_FLAG_STORE_PRED hands the caller's var_pred to the library for that purpose.                                     */
 int rk_solve_workspace_bytes(const rk_solve_cfg* cfg, int32_t mode, size_t* bytes);
 
 /* forward pass only: src/rodeo/solve.py:31-122 (_solve_filter).  out->mean_state/var_state <- filtered. */
@@ -214,7 +220,10 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
  * per block: obs (n_obs, d, n_bobs), obs_weight (n_obs, d, n_bobs, p), obs_var (n_obs, d, n_bobs, n_bobs) row-major on
  * device, shared by all trajectories; obs_ind (n_obs) = searchsorted(sim_times, obs_times), ascending.  logdens (B) is
  * overwritten.  The log-density follows src/rodeo/utils.py:60-78 (eigendecomposition of the forecast variance;
- * eigenvalues with |w| <= 1e-8 contribute nothing).                                                                 */
+ * eigenvalues with |w| <= 1e-8 contribute nothing).
+ * kalman_type = RK_KALMAN_SQRT (fenrir.py:292-296): `out` holds the batch-minor filtered means and FACTORS of the
+ * square-root rk_solve_filter (no flags, no predictions: they are re-evaluated), prior_var and obs_var are lower
+ * factors; square_root.forecast squares its factor (square_root.py:343-344), so the value is the same log-likelihood.    */
 int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
                        int32_t n_obs, int32_t n_bobs, double* logdens);
@@ -222,7 +231,8 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* 
 /* Fenrir's data-adaptive solver (src/rodeo/inference/fenrir.py:333-457 `_smooth_mv`, `solve_mv`): mean and variance of
  * p(X_{0:N} | Z_{1:N}, Y_{0:M}).  Input as for rk_fenrir_backward with RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR; the
  * backward filter's moments are kept in `workspace` (rk_fenrir_workspace_bytes), the smoothing pass overwrites
- * out->mean_state / out->var_state (batch-minor (N+1, d, p [,p], B)) with the result.                              */
+ * out->mean_state / out->var_state (batch-minor (N+1, d, p [,p], B)) with the result.  RK_KALMAN_SQRT (fenrir.py:421-426):
+ * input as for the square-root rk_fenrir_backward, the result's var_state holds factors.                              */
 int rk_fenrir_workspace_bytes(const rk_solve_cfg* cfg, size_t* bytes);
 int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
@@ -232,7 +242,9 @@ int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* 
  * Batched versions of the nine functions of src/rodeo/kalmantv/standard.py (kalman_type = RK_KALMAN_STANDARD)
  * and src/rodeo/kalmantv/square_root.py (RK_KALMAN_SQRT).  n = batch size (the reference's vmap axis);
  * every array is batch-minor: vectors (n_state, n), matrices (rows, cols, n).  A NULL optional input means 0.
- * Names of the arguments are the reference's keyword names.                                                 */
+ * Names of the arguments are the reference's keyword names.  Any n_state up to 768: one lane per item up to 16, one
+ * 512-thread workgroup per item on the dense solver's GEMM / LU / QR blocks beyond (the reference's operators are
+ * size-agnostic, standard.py:31-60); the large-block path keeps a grow-only device scratch on the handle.              */
 typedef struct {
     int32_t n;            /* batch                                                                         */
     int32_t n_state;
