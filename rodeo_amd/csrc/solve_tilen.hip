@@ -1,7 +1,7 @@
 // Blocked MFMA-tile solver for n_bstate = 4 .. 8 (n_bmeas = 1): the general-n_deriv form of the tile path.
 //
 //   src/rodeo/solve.py:31-122   _solve_filter -> fwd_tilen_kernel        (solve_tilen_kernels.hpp) NB x NB tiles per block
-//   src/rodeo/solve.py:257-301  solve_mv      -> tilen_gain_kernel       time-parallel: one lane per (step, unit) item
+//   src/rodeo/solve.py:257-301  solve_mv      -> tilen_gain_cols_kernel  time-parallel: one 16-lane row per (step, unit) item
 //                                                + bwd_mv_tilen_kernel   the carry recursion on blocked MFMA tiles
 //   src/rodeo/solve.py:162-204  solve_sim     -> tilen_gain_kernel<SIM>  + bwd_sim_tilen_kernel
 //
@@ -18,6 +18,7 @@
 //     solve_mv :  [ G^T row-major (p*p) | Sigma-_{n+1} (p*p) | mu-_{n+1} (p) ]
 //     solve_sim:  [ G^T row-major (p*p) | mu-_{n+1} (p)      | mu_f + L z (p) ]      (n = N: G = 0, mu- = 0: the terminal draw)
 #include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "kalman_small.hpp"
 #include "mfma_tile.hpp"
@@ -151,14 +152,9 @@ __global__ void __launch_bounds__(64) tilen_gain_kernel(SolveArgs a, const doubl
     }
 }
 
-// ---- phase 2: the sequential chains on blocked tiles ---------------------------------------------------------------------
-// One wave = 4 units (lane = 16 r + 4 g + c).  The records of the next TN_RING - 1 steps are always in flight (static
-// register names in a fully unrolled ring, so hipcc counts vmcnt per load and the loop-carried slots need no copies).
-// All accesses are raw buffer loads / stores on a window over the wave's four units of one time row: lanes of the zero
-// padding (and of units past the end) carry an out-of-range offset, so their loads return 0.0 and their stores are
-// dropped -- no selects and no exec-mask branches in the step.
-constexpr int TN_RING = 4;        // (22 memory operations per step at NB = 2: the 6-bit vmcnt covers about three steps anyway)
+// ---- raw buffer accesses on a window (scalar base, per-lane byte offset; out-of-range lanes load 0.0 / store nothing) ----
 constexpr int TN_OOR = (int)0x80000000;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t rs, int off) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
@@ -174,6 +170,200 @@ __device__ __forceinline__ void buf_st(double d, __amdgpu_buffer_rsrc_t rs, int 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_window(const void* base, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
+
+// ---- phase 1 for solve_mv: one 16-lane DPP row per item, one matrix column per lane ----------------------------------------
+// The lane-per-item kernel above holds five p x p matrices per lane: 390 / 474 / 512 (+ 168 spilled) VGPRs at p = 6 / 7 / 8, one
+// wave per SIMD, and 2.2 / 4.3 / 9.0 ms on the headline shape against 0.3 ms of fp64 VALU work (solve_sim still uses it).  Here an item is a 16-lane
+// row of the wave (four items per wave: the four units of the chain wave, looped over a chunk of time steps), lane j < 8
+// holds COLUMN j of the p x p matrices and lane 8 + j column j of the right-hand sides, and whatever a lane needs from
+// another column comes through the DPP operand of a 64-bit FMA (v_fmac_f64_dpp row_newbcast:k = lane k of the own row):
+//     lanes 0..7 :  v = Sigma_f[:, j]   y = Q v = (Q Sigma_f)[:, j]      A[:, j] = sum_k y_k[:] Q[j][k] + R[:, j] = Sigma-[:, j]
+//     lanes 8..15:  v = Sigma_f[j, :]   y = Q v = (Sigma_f Q^T)[j, :]^T  = column j of T^T, the right-hand sides of utils.py:119
+// and the LU with partial pivoting of [Sigma- | T^T] runs with every lane on its own column: the pivot search in column k
+// is lane k's, the row index and the multipliers l_i reach the other lanes by row_newbcast:k, the row swaps are selects
+// on the lane's own 8 values.  Back substitution: the right-hand-side lanes read U[k][i] from lane i.  Every sum has the
+// terms and the order of the lane-per-item kernel (lu_factor_fwd / lu_back, mm / mm_nt of linalg_small.hpp): the records
+// are the same to the bit (tests/test_gpu_tilen.py compares the two kernels).  About 40 VGPRs per p instead of 60 per p.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int J>
+__device__ __forceinline__ void fmac_bc(double& acc, double x, double y) {          // acc += x(lane J of the row) * y
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+}
+template <int J>
+__device__ __forceinline__ void fnmac_bc(double& acc, double x, double y) {         // acc -= x(lane J of the row) * y
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(J));
+}
+// A VALU write of a VGPR needs two wait states before a DPP operand reads it, and nothing checks that for inline
+// assembly: this ties the values to an s_nop, so that their producers stay in front of it and the DPP reads behind.
+template <int P>
+__device__ __forceinline__ void dpp_fence(double (&x)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) asm volatile("" : "+v"(x[i]));
+    asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < P; ++i) asm volatile("" : "+v"(x[i]));
+}
+template <int J>
+__device__ __forceinline__ double row_bc(double x) {                                // lane J of the row, in every lane
+    int lo_ = __double2loint(x), hi_ = __double2hiint(x);
+    lo_ = __builtin_amdgcn_mov_dpp(lo_, 0x150 + J, 0xF, 0xF, false);
+    hi_ = __builtin_amdgcn_mov_dpp(hi_, 0x150 + J, 0xF, 0xF, false);
+    return __hiloint2double(hi_, lo_);
+}
+
+template <int P>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+tilen_gain_cols_kernel(SolveArgs a, const double* __restrict__ tiles, double* __restrict__ ws, int n_first, int n_last, int chunk) {
+    static_assert(P >= 2 && P <= 8, "one column per lane: p <= 8");
+    constexpr int PP = P * P + P, RS0 = 2 * P * P + P, RS = RS0 + (RS0 & 1);
+    const int n_units = a.B * a.D, lane = threadIdx.x, g = lane >> 4, h = (lane >> 3) & 1, j = lane & 7;
+    const int n_valid = n_units - (int)blockIdx.x * 4 < 4 ? n_units - (int)blockIdx.x * 4 : 4;
+    const bool live = g < n_valid && j < P;
+    const int tau_raw = blockIdx.x * 4 + g, tau = tau_raw < n_units ? tau_raw : n_units - 1, jj = j < P ? j : P - 1;
+    const int b = tau / a.D, blk = tau - b * a.D;
+    double Qc[P], Qr[P], Rc[P];                           // Q[:, j], Q[j, :], R[:, j]
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        Qc[i] = ld(a.Q, ((size_t)blk * P + i) * P + jj, a.Q_b, a.B, b);
+        Qr[i] = ld(a.Q, ((size_t)blk * P + jj) * P + i, a.Q_b, a.B, b);
+        Rc[i] = ld(a.R, ((size_t)blk * P + i) * P + jj, a.R_b, a.B, b);
+    }
+    // The wave's four tiles of a time row (4 PP doubles) and its four records (4 RS doubles) are contiguous in HBM: whole rows
+    // move with 16 bytes per lane (3 + 5 instructions per item at p = 8 where one access per lane and matrix row took 19 --
+    // the CU's one address path, ~40 cycles for 64 separate addresses, was what bounded the first version: 3.0 ms at p = 8,
+    // 1.9 ms at p = 5), and the lanes pick their columns out of LDS.  One wave per workgroup: LDS accesses of a wave
+    // execute in order, no barrier.  Rows past the last unit load as zeros and are not stored (buffer range).
+    constexpr int NLT = (4 * PP * 8 + 1023) / 1024, NLW = (4 * RS * 8 + 1023) / 1024;
+    constexpr int IN_D = NLT * 128, OUT_D = NLW * 128, DUMP = IN_D + OUT_D;
+    __shared__ __attribute__((aligned(16))) double sh[IN_D + OUT_D + 2];
+    double* const in = sh;
+    double* const out = sh + IN_D;
+    int iV[P], iOut[P];                                   // LDS indices (doubles)
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        iV[k] = g * PP + (h ? jj * P + k : k * P + jj);                             // Sigma_f[k][j] | Sigma_f[j][k]
+        iOut[k] = live ? IN_D + g * RS + (h ? 0 : P * P) + k * P + j : DUMP;        // G^T[k][j]     | Sigma-[k][j]
+    }
+    const int iMu = g * PP + P * P + jj;
+    const int iMp = (live && !h) ? IN_D + g * RS + 2 * P * P + j : DUMP;
+    const int iPad = (RS != RS0 && lane % 16 == 0) ? IN_D + g * RS + RS0 : DUMP;
+    const size_t tstride = (size_t)n_units * PP, wstride = (size_t)n_units * RS;
+    const double* const tw = tiles + (size_t)blockIdx.x * 4 * PP;
+    double* const ww = ws + (size_t)blockIdx.x * 4 * RS;
+    const int tbytes = n_valid * PP * 8, wbytes = n_valid * RS * 8;
+    const int n0 = n_first + (int)blockIdx.y * chunk, n1 = n0 + chunk - 1 < n_last ? n0 + chunk - 1 : n_last;
+    u32x4 row[NLT];
+    auto gload = [&](int n) {
+        const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)n * tstride, tbytes);
+#pragma unroll
+        for (int i = 0; i < NLT; ++i) row[i] = __builtin_amdgcn_raw_buffer_load_b128(t, 1024 * i + 16 * lane, 0, 0);
+    };
+    if (n0 <= n1) gload(n0);
+    for (int n = n0; n <= n1; ++n) {
+        // ---- y = Q v  (mm(Q, Sigma_f) column j | mm_nt(Sigma_f, Q) row j), mu- = Q mu_f  (standard.py:57-59, 175) ----
+        double v[P], mu;
+        {
+            u32x4* const dst = (u32x4*)in;
+#pragma unroll
+            for (int i = 0; i < NLT; ++i) dst[64 * i + lane] = row[i];
+#pragma unroll
+            for (int k = 0; k < P; ++k) v[k] = sh[iV[k]];
+            mu = sh[iMu];
+        }
+        if (n < n1) gload(n + 1);                         // (the next item's rows fly behind this item's arithmetic)
+        double y[P], mp = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) y[i] = 0.0;
+        static_for<0, P>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+#pragma unroll
+            for (int i = 0; i < P; ++i) fmac_bc<k>(y[i], Qc[i], v[k]);
+            fmac_bc<k>(mp, mu, Qr[k]);
+        });
+        // ---- Sigma- = (Q Sigma_f) Q^T + R: column j in the lanes 0..7; the others keep their right-hand-side column ----
+        double sp[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) sp[i] = 0.0;
+        dpp_fence<P>(y);
+        static_for<0, P>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+#pragma unroll
+            for (int i = 0; i < P; ++i) fmac_bc<k>(sp[i], y[i], Qr[k]);
+        });
+        double A[P], Sp[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            Sp[i] = sp[i] + Rc[i];
+            A[i] = h ? y[i] : Sp[i];
+        }
+        // ---- LU with partial pivoting of [Sigma- | T^T], one column per lane (lu_factor_fwd, utils.py:119) ----
+        double rpv[P];
+        static_for<0, P>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            int piv = k;
+            double best = fabs(A[k]);
+#pragma unroll
+            for (int i = k + 1; i < P; ++i) {
+                const double w = fabs(A[i]);
+                const bool gt = w > best;
+                best = gt ? w : best;
+                piv = gt ? i : piv;
+            }
+            piv = __builtin_amdgcn_mov_dpp(piv, 0x150 + k, 0xF, 0xF, false);        // column k's choice
+#pragma unroll
+            for (int i = k + 1; i < P; ++i) {
+                const bool sw = piv == i;
+                const double t = A[k];
+                A[k] = sw ? A[i] : t;
+                A[i] = sw ? t : A[i];
+            }
+            rpv[k] = fast_rcp(A[k]);                      // (lane k's is the pivot's)
+            if constexpr (k + 1 < P) {
+                double l[P - k - 1];
+#pragma unroll
+                for (int i = k + 1; i < P; ++i) l[i - k - 1] = A[i] * rpv[k];
+                dpp_fence<P - k - 1>(l);
+#pragma unroll
+                for (int i = k + 1; i < P; ++i) fnmac_bc<k>(A[i], l[i - k - 1], A[k]);
+            }
+        });
+        // ---- back substitution (lu_back): the right-hand-side lanes read U[k][i] from lane i's A[k] ----
+        dpp_fence<P>(A);
+        static_for<0, P>([&](auto KK) {
+            constexpr int k = P - 1 - decltype(KK)::value;
+            double s = A[k];
+            static_for<k + 1, P>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                fnmac_bc<i>(s, A[k], A[i]);
+            });
+            const double x = s * row_bc<k>(rpv[k]);
+            A[k] = h ? x : A[k];
+        });
+        // ---- the record [G^T | Sigma- | mu-] ----
+#pragma unroll
+        for (int i = 0; i < P; ++i) sh[iOut[i]] = h ? A[i] : Sp[i];
+        sh[iMp] = mp;
+        if constexpr (RS != RS0) sh[iPad] = 0.0;
+        const __amdgpu_buffer_rsrc_t w = buf_window(ww + (size_t)n * wstride, wbytes);
+        const u32x4* const src = (const u32x4*)out;
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) __builtin_amdgcn_raw_buffer_store_b128(src[64 * i + lane], w, 1024 * i + 16 * lane, 0, 0);
+    }
+}
+
+// ---- phase 2: the sequential chains on blocked tiles ---------------------------------------------------------------------
+// One wave = 4 units (lane = 16 r + 4 g + c).  The records of the next TN_RING - 1 steps are always in flight (static
+// register names in a fully unrolled ring, so hipcc counts vmcnt per load and the loop-carried slots need no copies).
+// All accesses are raw buffer loads / stores on a window over the wave's four units of one time row: lanes of the zero
+// padding (and of units past the end) carry an out-of-range offset, so their loads return 0.0 and their stores are
+// dropped -- no selects and no exec-mask branches in the step.
+constexpr int TN_RING = 4;        // (22 memory operations per step at NB = 2: the 6-bit vmcnt covers about three steps anyway)
 
 // At most 256 VGPRs (waves_per_eu): two chain waves per SIMD at larger batches.
 template <int NB>
@@ -282,7 +472,6 @@ bwd_mv_tilen_kernel(SolveArgs a, double* __restrict__ tiles, const double* __res
 // rows: 16-byte-per-lane raw buffer loads into registers TS_LA steps ahead, ds_write_b128 into a per-wave LDS slot, the tile
 // elements out of LDS in the D layout (padding lanes read a zero word), and the smoothed tiles back through LDS as one
 // coalesced 16-byte-per-lane store.  Same arithmetic in the same order as bwd_mv_tilen_kernel.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TS_LA = 4;                                   // steps of row loads in flight
 
 template <int P>
@@ -630,7 +819,21 @@ int tilen_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     // workgroups take every free slot and the two kernels mostly alternate.  A fused producer / consumer workgroup like the
     // p = 3 kernels: 2.76 ms at n_deriv = 5, 5.1 ms at 6 -- its producers need > 256 VGPRs, so one workgroup per CU and
     // two rounds; capped at 256 VGPRs they spill: 4.9 ms.  Both removed.)
-    {
+    // phase 1 of solve_mv: one 16-lane row per item (tilen_gain_cols_kernel).  Measured, headline shape, ms at n_bstate = 5 .. 8:
+    // one lane per item 1.27 / 2.20 / 4.32 / 9.00, rows of lanes 1.18 / 1.71 / 2.33 / 2.64 (profiles/r03_nderiv_times_v2.jsonl);
+    // RK_TILEN_GAIN = lanes | cols overrides the choice (both forms give the same bits: tests/test_gpu_tilen.py)
+    const char* const gforce = getenv("RK_TILEN_GAIN");      // (read per call: the parity test switches it)
+    const bool cols = gforce ? gforce[0] == 'c' : true;
+    if (cols) {
+        constexpr int CHUNK = 32;                          // time steps per wave: the block constants are loaded once per chunk
+        const dim3 ggrid(div_up(n_units, 4), div_up(steps, CHUNK));
+        LaunchTimer t(h, "tilen_gain_cols_kernel");
+#define RK_COLS(P_) case P_: hipLaunchKernelGGL((tilen_gain_cols_kernel<P_>), ggrid, cblock, 0, h->stream, a, tiles, ws, 1, steps, CHUNK); break;
+        switch (P) { RK_COLS(4) RK_COLS(5) RK_COLS(6) RK_COLS(7) RK_COLS(8) }
+#undef RK_COLS
+        t.stop();
+        RK_HIP(hipGetLastError());
+    } else {
         LaunchTimer t(h, "tilen_gain_kernel");
         rc = launch_gain(h->stream, 1, steps);
         t.stop();

@@ -229,6 +229,32 @@ def test_blocked_tiles_chain_variants_agree(ra):
     assert res["rows"] == res["scattered"], res
 
 
+@pytest.mark.parametrize("p", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("B,N", [(5, 37), (1, 70), (2, 2)])
+def test_blocked_tiles_gain_variants_agree(ra, p, B, N, monkeypatch):
+    """The two forms of the time-parallel gain items of solve_mv (one lane per item; one 16-lane DPP row per item with a
+    matrix column per lane, rodeo_amd/csrc/solve_tilen.hip tilen_gain_cols_kernel) sum the same terms in the same order:
+    the smoothed means and variances are the same to the bit, at ragged unit counts (10 units = 2.5 waves) and across
+    the 32-step chunks of the column form.  RK_TILEN_GAIN is read per call."""
+    s = _fitz(ra, p, B=B, N=N, t_max=0.01 * N)
+    plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, s["t_max"], s["N"], ra.interrogate.interrogate_kramer,
+                        s["prior"], theta=s["theta"])
+    res = {}
+    for form in ("lanes", "cols"):
+        monkeypatch.setenv("RK_TILEN_GAIN", form)
+        plan.dev.profile_enable(True)
+        plan.mv(None)
+        m, v = plan.state_host()
+        names = [k for k, _ in plan.dev.profile_last()]
+        plan.dev.profile_enable(False)
+        if N >= 2 and p >= 5:                            # (p = 4 solve_mv: the hand-trimmed kernels of solve_tile4.hip)
+            assert ("tilen_gain_cols_kernel" in names) == (form == "cols"), names
+        res[form] = (np.array(m), np.array(v))
+    assert np.all(np.isfinite(res["cols"][0])) and np.all(np.isfinite(res["cols"][1]))
+    np.testing.assert_array_equal(res["lanes"][0], res["cols"][0])
+    np.testing.assert_array_equal(res["lanes"][1], res["cols"][1])
+
+
 @pytest.mark.parametrize("p,rhs", [(5, "lorenz63"), (6, "lorenz63"), (6, "higher_order"), (8, "higher_order")])
 def test_blocked_tiles_other_block_counts(ra, p, rhs):
     """n_block = 3 (one trajectory per wave, three units) and n_block = 1 (four trajectories per wave)."""
