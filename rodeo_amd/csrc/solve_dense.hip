@@ -36,6 +36,7 @@
 // 7 TB/s aggregate.  Next step would be an LU whose [Sigma^- | T^T] stays in registers (200 tiles over 8 waves).
 // Phase timing: build with -DRK_DENSE_STAMPS, run scripts/bench_configs.py c5 with RK_DENSE_STAMPS=1.
 #include <type_traits>
+#include <cstdlib>
 #include "common.hpp"
 #include "linalg_small.hpp"
 #include "solve_args.hpp"
@@ -1374,6 +1375,11 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
         a.ws_stride = dense_sq_ws_doubles(a.p, a.m);
         if (c->flags & RK_FLAG_STORE_PRED) a.fac_pred = out->var_pred;
         else if (dense_sqrt_keeps_pred_in_ws(c, mode)) a.fac_pred = a.ws + a.ws_stride * (size_t)a.B;
+        {   // structure of the predict stack (RK_DENSE_STRUCTURED=0: always the generic QR -- the parity test's other leg)
+            const char* const st = getenv("RK_DENSE_STRUCTURED");
+            if (st && st[0] == '0') RK_HIP(hipMemsetAsync(a.ws + a.ws_stride - 1, 0, sizeof(double), h->stream));
+            else hipLaunchKernelGGL(dense_sqcheck_kernel, dim3(1), dim3(256), 0, h->stream, a.Q, a.R, a.p, a.p / a.m, a.ws + a.ws_stride - 1);
+        }
         if (c->rhs_id == RK_RHS_LINEAR_DENSE) {
             LaunchTimer t(h, "dense_sqrt_fwd_kernel");
             hipLaunchKernelGGL((dense_sqrt_fwd_kernel<0>), dim3(a.B), dim3(DT), 0, h->stream, a);

@@ -169,9 +169,11 @@ __device__ __forceinline__ void qr_panel_cols(double (&tr)[16], double (&ta)[RT]
 // Factors the panel P (Mk <= 16 + 16 RT rows, nb <= 16 columns, row stride ld, in global memory): R11's upper triangle back
 // to P, V (unit lower trapezoid, explicit ones and zeros; zero rows up to the next multiple of 16) to the LDS panel
 // g_lds[r * LU_LD + c], tau to g_lds[tau_off ..].  Thread t < 256: column c = t & 15 of slab s = t >> 4 (16 slabs).
+// Pt: the panel's rows from the 17th on (P + 16 ld, or -- stacked triangular block on top, wg_qr_r -- the other block).
 template <int RT>
-__device__ __forceinline__ void qr_panel_body(double* P_, int ld_, int Mk_, int nb_, int pg_off_, int tau_off_) {
+__device__ __forceinline__ void qr_panel_body(double* P_, const double* Pt_, int ld_, int Mk_, int nb_, int pg_off_, int tau_off_) {
     auto* const P = uni_g(P_);
+    auto* const Pt = uni_g(Pt_);
     const int ld = uni(ld_), Mk = uni(Mk_), nb = uni(nb_), pg_off = uni(pg_off_), tau_off = uni(tau_off_);
     const int tid = threadIdx.x, c = tid & 15, s = tid >> 4, lane = tid & 63, wave = uni((int)(tid >> 6));
     const bool act = wave < QR_PW;
@@ -182,7 +184,7 @@ __device__ __forceinline__ void qr_panel_body(double* P_, int ld_, int Mk_, int 
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const int r = 16 + s + 16 * i;
-            ta[i] = (c < nb && r < Mk) ? P[(size_t)r * ld + c] : 0.0;
+            ta[i] = (c < nb && r < Mk) ? Pt[(size_t)(r - 16) * ld + c] : 0.0;
         }
     }
     qr_panel_cols<RT, 0>(tr, ta, myscale, act, c, wave, lane, nb, pg_off, tau_off);
@@ -204,8 +206,8 @@ __device__ __forceinline__ void qr_panel_body(double* P_, int ld_, int Mk_, int 
     for (int e = tid; e < (((Mk + 15) & ~15) - Mk) * 16; e += DT) panel[(Mk + (e >> 4)) * LU_LD + (e & 15)] = 0.0;   // whole tiles
     __syncthreads();
 }
-__device__ __noinline__ void qr_panel14(double* P, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<14>(P, ld, Mk, nb, pg_off, tau_off); }
-__device__ __noinline__ void qr_panel30(double* P, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<QR_RT>(P, ld, Mk, nb, pg_off, tau_off); }
+__device__ __noinline__ void qr_panel14(double* P, const double* Pt, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<14>(P, Pt, ld, Mk, nb, pg_off, tau_off); }
+__device__ __noinline__ void qr_panel30(double* P, const double* Pt, int ld, int Mk, int nb, int pg_off, int tau_off) { qr_panel_body<QR_RT>(P, Pt, ld, Mk, nb, pg_off, tau_off); }
 
 // T (16 x 16 upper triangular, g_lds[t_off + i * 16 + j]) of the compact WY form from the LDS panel V and tau:
 // T_jj = tau_j, T(0:j, j) = -tau_j T(0:j, 0:j) (V^T V)(0:j, j)   (LAPACK dlarft, forward / columnwise).
@@ -254,8 +256,10 @@ __device__ __noinline__ void qr_build_T(int Mk_, int gp_off_, int t_off_, int ta
 // per round, buffers alternate), forms W' = T^T W with four MFMAs (W's accumulator is again a B fragment), applies
 // tile -= V_rows W' onto the registers it still holds and stores them: every element of A2 is read once and written once.
 constexpr int QF_T = 16;                                // row tiles per unit: panels of up to 512 rows
-__device__ __noinline__ void qr_fused_update(double* A2_, int lda_, int Mk_, int n2_, int t_off_, int px_off_) {
+// A2t: A2's rows from the 17th on (A2 + 16 lda, or the other block of a stack with its triangular block on top).
+__device__ __noinline__ void qr_fused_update(double* A2_, double* A2t_, int lda_, int Mk_, int n2_, int t_off_, int px_off_) {
     auto* const A2 = uni_g(A2_);
+    auto* const A2t = uni_g(A2t_);
     const int lda = uni(lda_), Mk = uni(Mk_), n2 = uni(n2_), t_off = uni(t_off_), px_off = uni(px_off_);
     const double* const panel = g_lds;                                // rows Mk .. 16 nrt - 1 are zero (qr_panel_body)
     const double* const T = g_lds + t_off;
@@ -273,7 +277,6 @@ __device__ __noinline__ void qr_fused_update(double* A2_, int lda_, int Mk_, int
         // Addresses: a scalar row-tile base plus four per-lane offsets (rows 4v + hi of a tile, column j).  No load is
         // masked (a select behind a load makes hipcc wait for that load at once): a row past the end reads the last row,
         // a column past the end column 0 -- finite values of the matrix that meet zero rows of V and are never stored.
-        gd* const base = A2 + (size_t)(16 * rb0) * lda;
         const int rows_left = Mk - 16 * rb0;
         const int jc = cok ? j : 0;
         int voff[4];
@@ -283,7 +286,7 @@ __device__ __noinline__ void qr_fused_update(double* A2_, int lda_, int Mk_, int
 #pragma unroll
         for (int q = 0; q < QF_T; ++q) {
             if (q < nq) {
-                gd* const tb = base + (size_t)(16 * q) * lda;                  // scalar
+                gd* const tb = rb0 + q == 0 ? A2 : A2t + (size_t)(16 * (rb0 + q - 1)) * lda;     // scalar
                 const int rl = rows_left - 16 * q;                            // rows of this tile that exist (>= 1)
                 if (rl >= 16) {
 #pragma unroll
@@ -324,7 +327,7 @@ __device__ __noinline__ void qr_fused_update(double* A2_, int lda_, int Mk_, int
 #pragma unroll
                     for (int kq = 0; kq < 4; ++kq)
                         t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-eb[16 * q * LU_LD + 4 * kq], wp[kq], t[q], 0, 0, 0);
-                    gd* const tb = base + (size_t)(16 * q) * lda;
+                    gd* const tb = rb0 + q == 0 ? A2 : A2t + (size_t)(16 * (rb0 + q - 1)) * lda;
                     const int rl = rows_left - 16 * q;
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
@@ -374,25 +377,43 @@ __device__ __noinline__ void wg_qr_r_unblocked(double* S_, int ld_, int M_, int 
 
 // In place: the upper triangle of the top n x n block of S (M x n, row stride ld, M >= 1) becomes the R of S's QR
 // factorisation (LAPACK's sign convention: r_jj = -sign(a_jj) ||.||); everything below the diagonal is left undefined.
-__device__ __noinline__ void wg_qr_r(double* S_, int ld_, int M_, int n_, double* ws_end_ = nullptr) {
+//
+// tp_top = n > 0 (n a multiple of 16): S = [T ; A] with T (n x n) UPPER TRIANGULAR on top -- add_sqrt's stack with the
+// transposed lower factor first (the R of a stack does not depend on the order of its rows).  The reflectors of panel k
+// then have their support in T's rows 16 k .. 16 k + 15 and in A: T's rows below are zero in the panel's columns and stay
+// out of the panel, of T and of the update (LAPACK's dtpqrt: 2 n^3 instead of 3.33 n^3 flops for A of n rows).
+// nd > 0 on top of that: A is BLOCK upper triangular with nd x nd blocks (A = (Q L)^T for a lower triangular L and a
+// block-diagonal Q, prior.indep_init: A[i][j] = sum_k L[k][i] Q[j][k] needs a k >= i in j's block), so in the columns
+// of panel k only A's rows up to the end of the block of column 16 k + 15 are non-zero: the panel's row count grows from
+// 16 + nd ... to 16 + n instead of shrinking from 2 n (0.31 of the generic tile count at n = 160, nd = 5).
+__device__ __noinline__ void wg_qr_r(double* S_, int ld_, int M_, int n_, double* ws_end_ = nullptr, int tp_top_ = 0, int nd_ = 0) {
     auto* const S = uni_g(S_);
     auto* const ws_end = uni_g(ws_end_);
     (void)ws_end;
-    const int ld = uni(ld_), M = uni(M_), n = uni(n_);
+    const int ld = uni(ld_), M = uni(M_), n = uni(n_), nd = uni(nd_);
+    const int tp = (uni(tp_top_) == n && (n & 15) == 0 && M > n) ? n : 0;       // (anything else: the generic path, correct for any S)
     RK_STAMP_DECL(ws_end);
-    const int gp_off = (((M + 15) & ~15) * LU_LD + 1) & ~1, t_off = gp_off + NWAVE * 256, tau_off = t_off + 256, pg_off = tau_off + 16;
+    const int Mmax = tp ? 16 + (M - tp) : M;
+    const int gp_off = (((Mmax + 15) & ~15) * LU_LD + 1) & ~1, t_off = gp_off + NWAVE * 256, tau_off = t_off + 256, pg_off = tau_off + 16;
     const int px_off = pg_off + 2 * 16 * QR_PW;                // partial W tiles of the fused update: 2 x 8 x 256
-    if (M > QR_MAXM || px_off + 2 * NWAVE * 256 > LDS_DOUBLES) { wg_qr_r_unblocked((double*)S, ld, M, n); return; }
+    if (Mmax > QR_MAXM || px_off + 2 * NWAVE * 256 > LDS_DOUBLES) { wg_qr_r_unblocked((double*)S, ld, M, n); return; }
     __syncthreads();
     for (int k0 = 0; k0 < n && k0 < M; k0 += 16) {
-        const int nb = min(16, n - k0), Mk = M - k0, n2 = n - k0 - nb;
-        if (Mk <= 16 + 16 * 14) qr_panel14((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
-        else qr_panel30((double*)(S + (size_t)k0 * ld + k0), ld, Mk, nb, pg_off, tau_off);
+        const int nb = min(16, n - k0), n2 = n - k0 - nb;
+        int Mk = M - k0;
+        double* Pt = (double*)(S + (size_t)(k0 + 16) * ld + k0);
+        if (tp) {
+            const int mb = M - tp, rl = nd > 0 ? min(mb, ((k0 + nb - 1) / nd + 1) * nd) : mb;
+            Mk = 16 + rl;
+            Pt = (double*)(S + (size_t)tp * ld + k0);
+        }
+        if (Mk <= 16 + 16 * 14) qr_panel14((double*)(S + (size_t)k0 * ld + k0), Pt, ld, Mk, nb, pg_off, tau_off);
+        else qr_panel30((double*)(S + (size_t)k0 * ld + k0), Pt, ld, Mk, nb, pg_off, tau_off);
         RK_STAMP(10);
         if (n2 > 0) {
             qr_build_T(Mk, gp_off, t_off, tau_off);
             RK_STAMP(11);
-            qr_fused_update((double*)(S + (size_t)k0 * ld + k0 + nb), ld, Mk, n2, t_off, px_off);
+            qr_fused_update((double*)(S + (size_t)k0 * ld + k0 + nb), Pt + nb, ld, Mk, n2, t_off, px_off);
             RK_STAMP(13);
         }
     }
@@ -565,6 +586,23 @@ size_t dense_sq_ws_doubles(int p, int m) {
     return dense_sq_off_mup(p, m) + 2 * (size_t)p + 2 * (size_t)m + 16;
 }
 
+// 1.0 if the predict step's stack has the structure wg_qr_r can use: every entry of Q outside the nd x nd diagonal blocks and
+// every entry of R^{1/2} above the diagonal exactly zero, p a multiple of 16 (what prior.indep_init + a Cholesky factor give)
+__global__ void dense_sqcheck_kernel(const double* Q, const double* Rh, int p, int nd, double* flag) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int e = threadIdx.x; e < p * p; e += blockDim.x) {
+        const int i = e / p, j = e - i * p;
+        if (i / nd != j / nd && Q[e] != 0.0) mine = 1;
+        if (j > i && Rh[e] != 0.0) mine = 1;
+    }
+    if (mine) atomicOr(&bad, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = (bad || (p & 15) || nd < 1 || p % nd) ? 0.0 : 1.0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Forward pass, square-root form (solve.py:31-122 with square_root.py:56-57 and 88-99).  MODE as in dense_fwd_kernel.
 // a.var: the filtered factors L_n (lower), a.fac_pred: the predicted factors L^-_n (or null: not kept).
@@ -583,6 +621,8 @@ __global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
     const int kv = noisy ? m : 0;
     double* const ws_end = a.ws + a.ws_stride;                     // (phase stamps of workgroup 0, -DRK_DENSE_STAMPS)
     (void)ws_end;
+    // set by dense_sqcheck_kernel: Q block diagonal (nd x nd), R^{1/2} lower triangular, p a multiple of 16 (indep_init priors)
+    const bool structured = a.ws[a.ws_stride - 1] != 0.0;
     RK_STAMP_DECL(ws_end);
     if (MODE != 2) {
         RK_STAMP_ZERO_N(15);
@@ -597,11 +637,12 @@ __global__ void __launch_bounds__(DT) dense_sqrt_fwd_kernel(DenseArgs a) {
         const double* Ln = var + (size_t)n * p * p;
         double* Lp = facp ? facp + (size_t)(n + 1) * p * p : w.A2;
         // square_root.py:56-57: L^- = add_sqrt(Q L, R^{1/2}) = R^T of qr([ (Q L)^T ; R^{1/2 T} ])
+        // (structured: R^{1/2 T}, upper triangular, on top and the block upper triangular (Q L)^T below -- wg_qr_r)
         RK_STAMP_RESET();
-        wg_gemm(gemm_op(w.S, p, Ln, p, true, a.Q, p, true, p, p, p, nullptr, 0, 0.0, 1.0));
-        wg_transpose(w.S + (size_t)p * p, p, a.R, p, p, p, 0);
+        wg_gemm(gemm_op(w.S + (structured ? (size_t)p * p : 0), p, Ln, p, true, a.Q, p, true, p, p, p, nullptr, 0, 0.0, 1.0));
+        wg_transpose(w.S + (structured ? 0 : (size_t)p * p), p, a.R, p, p, p, 0);
         RK_STAMP(0);
-        wg_qr_r(w.S, p, 2 * p, p, ws_end);
+        wg_qr_r(w.S, p, 2 * p, p, ws_end, structured ? p : 0, structured ? nd : 0);
         RK_STAMP(1);
         wg_transpose(Lp, p, w.S, p, p, p, 1);
         wg_gemv<false>(w.mup, a.Q, p, mu, p, p, nullptr, 0.0, 1.0);

@@ -145,9 +145,11 @@ static int launch_fwd_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& 
 bool is_user_rhs(int rhs_id);
 int user_forward_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a);
 
-int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode) {
+int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a_, int mode) {
     RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 8, RK_ERR_UNSUPPORTED, "square-root solver supports n_bstate in [2, 8], got %d",
                c->n_bstate);
+    SolveArgs a = a_;
+    if (!(c->flags & RK_FLAG_STORE_PRED)) a.mean_pred = a.var_pred = nullptr;       // (the kernel stores predictions iff both are set)
     int rc;
     if (is_user_rhs(c->rhs_id)) rc = user_forward_sqrt(h, c, a);      // hiprtc build of fwd_sqrt_kernel (rhs_jit.hip)
     else switch (c->rhs_id) {

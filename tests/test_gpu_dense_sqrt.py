@@ -57,6 +57,7 @@ def _check(m, L, mo, Lo, tol_m, tol_v, Rh):
     (4, 3, "rodeo", 24), (4, 3, "kramer", 24), (4, 3, "schober", 24),            # p = 12: one QR panel, one row block
     (6, 3, "kramer", 24), (7, 5, "kramer", 12), (7, 5, "rodeo", 12),              # p = 18, 35: ragged panels
     (24, 3, "kramer", 8), (24, 3, "rodeo", 8),                                     # p = 72, m = 24
+    (16, 3, "kramer", 8), (16, 4, "schober", 8), (16, 5, "rodeo", 8),              # p = 48, 64, 80: the structured predict QR
     (32, 5, "kramer", 6)])                                                         # config 5's shape (p = 160, m = 32)
 def test_dense_sqrt_parity(ra, n_vars, n_deriv, itg, N):
     """solve_mv and the filter in square-root form against the oracle, and (exact measurement) against the covariance form."""
@@ -109,6 +110,42 @@ def test_dense_sqrt_sample_paths(ra):
     np.testing.assert_array_equal(x[:, 0], s["x0"])
     scale = np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1e-300)
     assert np.max(np.abs(x - xo) / scale) < 1e-7
+
+
+@pytest.mark.parametrize("n_vars,n_deriv", [(16, 3), (16, 5), (32, 5)])
+def test_dense_sqrt_structured_predict_qr(ra, n_vars, n_deriv, monkeypatch):
+    """The predict step's stack [R^(1/2)T ; (Q L)^T] of an indep_init prior is upper triangular over block upper triangular;
+    wg_qr_r (rodeo_amd/csrc/solve_dense_sqrt.hpp) leaves the structural zeros out of its panels.  Same factors as the generic
+    QR of the same stack (RK_DENSE_STRUCTURED=0) up to rounding, and a prior WITHOUT the structure (Q with an entry outside
+    its diagonal blocks; a full square root of R) takes the generic path by itself and still matches the oracle."""
+    N, B = 6, 2
+    t_max = N / 24.0
+    s = dense_problem(ra, n_vars, n_deriv, N, t_max, B=B)
+    ode_d, ode_o = ra.ode.linear_dense(n_vars, n_deriv), odes.make_linear_dense(s["A"], n_deriv)
+    p = n_vars * n_deriv
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RK_DENSE_STRUCTURED", flag)
+        plan = ra.SolvePlan(ode_d, s["W"], s["x0"], 0.0, t_max, N, ra.interrogate.interrogate_kramer, s["prior"],
+                            kalman_type="square-root", A=s["A"])
+        plan.mv(None)
+        res[flag] = plan.state_host()
+    monkeypatch.delenv("RK_DENSE_STRUCTURED")
+    _check(res["1"][0], res["1"][1], res["0"][0], res["0"][1], 1e-9, 1e-9, s["prior"][1])      # (2e-11 / 8e-14 measured at p = 160)
+    assert np.all(np.triu(res["1"][1], 1) == 0.0)
+    # a prior without the structure: Q coupled across two blocks, R's symmetric square root instead of its Cholesky factor
+    Q, Rh = s["prior"]                                   # (1, p, p): one block
+    Q2 = Q.copy(); Q2[0, 0, n_deriv] = 0.01 * Q[0, 0, 1]
+    w_, V_ = np.linalg.eigh(Rh[0] @ Rh[0].T)
+    Rsym = ((V_ * np.sqrt(w_)) @ V_.T)[None]
+    for prior in ((Q2, Rh), (Q, Rsym)):
+        plan = ra.SolvePlan(ode_d, s["W"], s["x0"], 0.0, t_max, N, ra.interrogate.interrogate_kramer, prior,
+                            kalman_type="square-root", A=s["A"])
+        plan.mv(None)
+        m, L = plan.state_host()
+        with threadpool_limits(limits=1):
+            mo, Lo = scan.solve_mv(None, ode_o, s["W"], s["x0"], 0.0, t_max, N, oi.interrogate_kramer, prior, kalman_type="square-root")
+        _check(m, L, mo, Lo, 1e-9, 1e-8, Rh)
 
 
 @pytest.mark.parametrize("n_vars,n_deriv,N", [(36, 5, 3), (44, 4, 3)])

@@ -450,6 +450,14 @@ def test_square_root_solver_parity(ra, name):
         m2, v2 = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, g, s["prior"], theta=s["theta"])
         assert np.max(np.abs(m - m2)) < 1e-7
         _vclose(_sq(L), v2, 1e-6)
+    # _solve_filter's four outputs in square-root form: predicted AND filtered means / factors (solve.py:114-121)
+    from rodeo_amd.solve import _solve_filter
+    f = _solve_filter(5, ra.ode.fitzhugh_nagumo, *args, g, *pr, kalman_funs=ra.kalmantv.square_root, theta=s["theta"])
+    fo = scan.solve_filter(5, odes.fitzhugh_nagumo, *args, o, *pr, kalman_funs=scan.sqrt_ops, theta=s["theta"])
+    for k in ("state_pred", "state_filt"):
+        assert np.max(np.abs(f[k][0] - fo[k][0])) < 1e-8
+        _vclose(_sq(f[k][1]), _sq(fo[k][1]), 1e-7)
+    np.testing.assert_array_equal(f["state_pred"][0][:, 0], s["x0"]); assert np.all(f["state_pred"][1][:, 0] == 0)
     x = ra.solve_sim(5, ra.ode.fitzhugh_nagumo, *args, g, pr, kalman_type="square-root", theta=s["theta"])
     xo = scan.solve_sim(5, odes.fitzhugh_nagumo, *args, o, pr, kalman_type="square-root", theta=s["theta"])
     assert x.shape == (B, N + 1, 2, 3) and np.all(np.isfinite(x))
@@ -462,6 +470,14 @@ def test_square_root_solver_parity(ra, name):
         # two QR implementations draw different (equally valid) paths; check the draw against the smoothed moments
         sd = np.sqrt(np.einsum("bnkii->bnki", _sq(L)))
         assert np.max(np.abs(x - m)[:, 1:] / (sd[:, 1:] + 1e-12)) < 8.0
+        if name == "schober":
+            # ... and a sharp property that every valid path shares: an exact measurement leaves no variance along W, in the
+            # filtered state (W Sigma_f = 0) and hence in the smoothing gain (W G = W Sigma_f Q^T S-^{-1} = 0) and in every
+            # conditional draw, so W x_n = W mu_f,n at every step -- the sampled path satisfies the filter's constraint
+            mf = f["state_filt"][0]
+            res = np.einsum("kp,bnkp->bnk", s["W"][:, 0, :], x - mf)[:, 1:]
+            scale = np.abs(np.einsum("kp,bnkp->bnk", np.abs(s["W"][:, 0, :]), np.abs(mf)))[:, 1:] + 1.0
+            assert np.max(np.abs(res) / scale) < 1e-9, np.max(np.abs(res) / scale)
 
 
 def test_square_root_higher_order_example(ra):
