@@ -222,7 +222,7 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
  * overwritten.  The log-density follows src/rodeo/utils.py:60-78 (eigendecomposition of the forecast variance;
  * eigenvalues with |w| <= 1e-8 contribute nothing).
  * kalman_type = RK_KALMAN_SQRT (fenrir.py:292-296): `out` holds the batch-minor filtered means and FACTORS of the
- * square-root rk_solve_filter (predictions are re-evaluated; RK_FLAG_STORE_PRED stores the predicted means and factors), prior_var and obs_var are lower
+ * square-root rk_solve_filter (no predictions needed: they are re-evaluated), prior_var and obs_var are lower
  * factors; square_root.forecast squares its factor (square_root.py:343-344), so the value is the same log-likelihood.    */
 int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,

@@ -217,6 +217,82 @@ __device__ __forceinline__ double row_bc(double x) {                            
     return __hiloint2double(hi_, lo_);
 }
 
+// One item (one 16-lane row): from this lane's column v of Sigma_f (lanes 0..7: column j, lanes 8..15: row j) and mu_f to
+// Sigma-[:, j] (Sp, lanes 0..7), mu-_j (mp, lanes 0..7) and column j of G^T (A, lanes 8..15).
+template <int P>
+__device__ __forceinline__ void cols_gain_item(const double (&Qc)[P], const double (&Qr)[P], const double (&Rc)[P], int h,
+                                               const double (&v)[P], double mu, double (&A)[P], double (&Sp)[P], double& mp) {
+    // ---- y = Q v  (mm(Q, Sigma_f) column j | mm_nt(Sigma_f, Q) row j), mu- = Q mu_f  (standard.py:57-59, 175) ----
+    double y[P];
+    mp = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) y[i] = 0.0;
+    static_for<0, P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+#pragma unroll
+        for (int i = 0; i < P; ++i) fmac_bc<k>(y[i], Qc[i], v[k]);
+        fmac_bc<k>(mp, mu, Qr[k]);
+    });
+    // ---- Sigma- = (Q Sigma_f) Q^T + R: column j in the lanes 0..7; the others keep their right-hand-side column ----
+    double sp[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) sp[i] = 0.0;
+    dpp_fence<P>(y);
+    static_for<0, P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+#pragma unroll
+        for (int i = 0; i < P; ++i) fmac_bc<k>(sp[i], y[i], Qr[k]);
+    });
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        Sp[i] = sp[i] + Rc[i];
+        A[i] = h ? y[i] : Sp[i];
+    }
+    // ---- LU with partial pivoting of [Sigma- | T^T], one column per lane (lu_factor_fwd, utils.py:119) ----
+    double rpv[P];
+    static_for<0, P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        int piv = k;
+        double best = fabs(A[k]);
+#pragma unroll
+        for (int i = k + 1; i < P; ++i) {
+            const double w = fabs(A[i]);
+            const bool gt = w > best;
+            best = gt ? w : best;
+            piv = gt ? i : piv;
+        }
+        piv = __builtin_amdgcn_mov_dpp(piv, 0x150 + k, 0xF, 0xF, false);        // column k's choice
+#pragma unroll
+        for (int i = k + 1; i < P; ++i) {
+            const bool sw = piv == i;
+            const double t = A[k];
+            A[k] = sw ? A[i] : t;
+            A[i] = sw ? t : A[i];
+        }
+        rpv[k] = fast_rcp(A[k]);                      // (lane k's is the pivot's)
+        if constexpr (k + 1 < P) {
+            double l[P - k - 1];
+#pragma unroll
+            for (int i = k + 1; i < P; ++i) l[i - k - 1] = A[i] * rpv[k];
+            dpp_fence<P - k - 1>(l);
+#pragma unroll
+            for (int i = k + 1; i < P; ++i) fnmac_bc<k>(A[i], l[i - k - 1], A[k]);
+        }
+    });
+    // ---- back substitution (lu_back): the right-hand-side lanes read U[k][i] from lane i's A[k] ----
+    dpp_fence<P>(A);
+    static_for<0, P>([&](auto KK) {
+        constexpr int k = P - 1 - decltype(KK)::value;
+        double s = A[k];
+        static_for<k + 1, P>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            fnmac_bc<i>(s, A[k], A[i]);
+        });
+        const double x = s * row_bc<k>(rpv[k]);
+        A[k] = h ? x : A[k];
+    });
+}
+
 template <int P>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 tilen_gain_cols_kernel(SolveArgs a, const double* __restrict__ tiles, double* __restrict__ ws, int n_first, int n_last, int chunk) {
@@ -266,7 +342,6 @@ tilen_gain_cols_kernel(SolveArgs a, const double* __restrict__ tiles, double* __
     };
     if (n0 <= n1) gload(n0);
     for (int n = n0; n <= n1; ++n) {
-        // ---- y = Q v  (mm(Q, Sigma_f) column j | mm_nt(Sigma_f, Q) row j), mu- = Q mu_f  (standard.py:57-59, 175) ----
         double v[P], mu;
         {
             u32x4* const dst = (u32x4*)in;
@@ -277,74 +352,8 @@ tilen_gain_cols_kernel(SolveArgs a, const double* __restrict__ tiles, double* __
             mu = sh[iMu];
         }
         if (n < n1) gload(n + 1);                         // (the next item's rows fly behind this item's arithmetic)
-        double y[P], mp = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) y[i] = 0.0;
-        static_for<0, P>([&](auto K) {
-            constexpr int k = decltype(K)::value;
-#pragma unroll
-            for (int i = 0; i < P; ++i) fmac_bc<k>(y[i], Qc[i], v[k]);
-            fmac_bc<k>(mp, mu, Qr[k]);
-        });
-        // ---- Sigma- = (Q Sigma_f) Q^T + R: column j in the lanes 0..7; the others keep their right-hand-side column ----
-        double sp[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) sp[i] = 0.0;
-        dpp_fence<P>(y);
-        static_for<0, P>([&](auto K) {
-            constexpr int k = decltype(K)::value;
-#pragma unroll
-            for (int i = 0; i < P; ++i) fmac_bc<k>(sp[i], y[i], Qr[k]);
-        });
-        double A[P], Sp[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            Sp[i] = sp[i] + Rc[i];
-            A[i] = h ? y[i] : Sp[i];
-        }
-        // ---- LU with partial pivoting of [Sigma- | T^T], one column per lane (lu_factor_fwd, utils.py:119) ----
-        double rpv[P];
-        static_for<0, P>([&](auto K) {
-            constexpr int k = decltype(K)::value;
-            int piv = k;
-            double best = fabs(A[k]);
-#pragma unroll
-            for (int i = k + 1; i < P; ++i) {
-                const double w = fabs(A[i]);
-                const bool gt = w > best;
-                best = gt ? w : best;
-                piv = gt ? i : piv;
-            }
-            piv = __builtin_amdgcn_mov_dpp(piv, 0x150 + k, 0xF, 0xF, false);        // column k's choice
-#pragma unroll
-            for (int i = k + 1; i < P; ++i) {
-                const bool sw = piv == i;
-                const double t = A[k];
-                A[k] = sw ? A[i] : t;
-                A[i] = sw ? t : A[i];
-            }
-            rpv[k] = fast_rcp(A[k]);                      // (lane k's is the pivot's)
-            if constexpr (k + 1 < P) {
-                double l[P - k - 1];
-#pragma unroll
-                for (int i = k + 1; i < P; ++i) l[i - k - 1] = A[i] * rpv[k];
-                dpp_fence<P - k - 1>(l);
-#pragma unroll
-                for (int i = k + 1; i < P; ++i) fnmac_bc<k>(A[i], l[i - k - 1], A[k]);
-            }
-        });
-        // ---- back substitution (lu_back): the right-hand-side lanes read U[k][i] from lane i's A[k] ----
-        dpp_fence<P>(A);
-        static_for<0, P>([&](auto KK) {
-            constexpr int k = P - 1 - decltype(KK)::value;
-            double s = A[k];
-            static_for<k + 1, P>([&](auto I) {
-                constexpr int i = decltype(I)::value;
-                fnmac_bc<i>(s, A[k], A[i]);
-            });
-            const double x = s * row_bc<k>(rpv[k]);
-            A[k] = h ? x : A[k];
-        });
+        double A[P], Sp[P], mp;
+        cols_gain_item<P>(Qc, Qr, Rc, h, v, mu, A, Sp, mp);
         // ---- the record [G^T | Sigma- | mu-] ----
 #pragma unroll
         for (int i = 0; i < P; ++i) sh[iOut[i]] = h ? A[i] : Sp[i];
@@ -617,6 +626,224 @@ bwd_mv_tilen_rows_kernel(SolveArgs a, double* __restrict__ tiles, const double* 
     }
 }
 
+// ---- solve_mv backward pass in ONE kernel: the chain wave fed through LDS by two gain waves ------------------------------------
+// The two-kernel form writes a record of 2 p^2 + p doubles per (step, unit) to HBM and reads it back (3.4 x the backward pass's
+// algorithmic traffic, profiles/r03_nderiv5_pmc_traffic.json), and its chain spends most of its step on the 16 scattered loads
+// that fetch the record.  Here a workgroup is four units: wave 0 runs the chain of bwd_mv_tilen_kernel, waves 1 and 2 produce
+// the records of the next chunk of FZ_C time steps (cols_gain_item: a 16-lane row per unit, alternate steps) straight into
+// LDS, double-buffered, one barrier per chunk; the filtered tiles they load as whole rows stay in LDS for the chain too, so
+// the chain's only memory instructions are LDS reads and the stores of the smoothed tiles.  HBM sees the filtered tiles once
+// and the smoothed tiles once.  The producers run ahead of the chain (lower n), so the in-place stores never meet a load.
+constexpr int FZ_C = 4;                                   // time steps per chunk
+
+template <int P, int NPROD>
+__global__ void __launch_bounds__(64 * (1 + NPROD)) __attribute__((amdgpu_waves_per_eu(2)))
+bwd_mv_tilen_fused_kernel(SolveArgs a, double* __restrict__ tiles, int n_top, int n_bot, double* dbg) {
+    static_assert(P >= 5 && P <= 8, "blocked tiles with NB = 2");
+    // dbg (RK_TILEN_STAMPS=1, workgroup 0 only): per wave [cycles of work, cycles at the chunk barriers] (s_memtime)
+    uint64_t t_work = 0, t_wait = 0, t0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](uint64_t& acc) { if (dbg) { const uint64_t t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; } };
+    static_assert(FZ_C % NPROD == 0, "every producer wave has the same slots in every chunk");
+    constexpr int NT = 64 * (1 + NPROD);
+    constexpr int NB = 2, PP = P * P + P, RS0 = 2 * P * P + P, RS = RS0 + (RS0 & 1);
+    constexpr int NLT = (4 * PP * 8 + 1023) / 1024, TW = NLT * 128;         // a staged tile row: whole 16-byte-per-lane loads
+    static_assert(4 * PP < TW, "the tail of a staged tile row is the zero word of the chain's padding lanes");
+    constexpr int RW = 4 * RS + 2;                                          // a record row + [dump word, zero word]
+    constexpr int REC = 0, TIL = 2 * FZ_C * RW, TOTAL = TIL + 2 * FZ_C * TW;
+    __shared__ __attribute__((aligned(16))) double sh[TOTAL];
+    const int n_units = a.B * a.D, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_valid = n_units - (int)blockIdx.x * 4 < 4 ? n_units - (int)blockIdx.x * 4 : 4;
+    const size_t tstride = (size_t)n_units * PP;
+    double* const tw = tiles + (size_t)blockIdx.x * 4 * PP;
+    const int tbytes = n_valid * PP * 8;
+    const int nch = (n_top - n_bot + FZ_C) / FZ_C;                           // chunks of this launch
+    for (int e = threadIdx.x; e < 2 * FZ_C; e += NT) sh[REC + e * RW + 4 * RS + 1] = 0.0;      // the records' zero words
+    __syncthreads();
+    if (wave != 0) {
+        // ================= producers: wave 1 + pw has the slots pw, pw + NPROD, ... of every chunk =================
+        const int pw = wave - 1, g = lane >> 4, h = (lane >> 3) & 1, j = lane & 7;
+        const int tau_raw = blockIdx.x * 4 + g, tau = tau_raw < n_units ? tau_raw : n_units - 1, jj = j < P ? j : P - 1;
+        const int b = tau / a.D, blk = tau - b * a.D;
+        double Qc[P], Qr[P], Rc[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            Qc[i] = ld(a.Q, ((size_t)blk * P + i) * P + jj, a.Q_b, a.B, b);
+            Qr[i] = ld(a.Q, ((size_t)blk * P + jj) * P + i, a.Q_b, a.B, b);
+            Rc[i] = ld(a.R, ((size_t)blk * P + i) * P + jj, a.R_b, a.B, b);
+        }
+        int iV[P], iOut[P];                               // indices inside a tile slot / a record slot
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            iV[k] = g * PP + (h ? jj * P + k : k * P + jj);
+            iOut[k] = j < P ? g * RS + (h ? 0 : P * P) + k * P + j : 4 * RS;         // (lanes without a column: the dump word)
+        }
+        const int iMu = g * PP + P * P + jj;
+        const int iMp = (j < P && !h) ? g * RS + 2 * P * P + j : 4 * RS;
+        const int iPad = (RS != RS0 && lane % 16 == 0) ? g * RS + RS0 : 4 * RS;
+        u32x4 row[NLT];
+        auto gload = [&](int n) {
+            const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)n * tstride, tbytes);
+#pragma unroll
+            for (int i = 0; i < NLT; ++i) row[i] = __builtin_amdgcn_raw_buffer_load_b128(t, 1024 * i + 16 * lane, 0, 0);
+        };
+        // this wave's steps: n_top - pw, n_top - pw - NPROD, ... (the pattern runs through the chunk boundaries)
+        if (n_top - pw >= n_bot) gload(n_top - pw);
+        // iteration ch (re)fills the slots of buffer ch & 1 for chunk ch; what the chain left there two chunks ago -- the smoothed
+        // tiles of chunk ch - 2, written in place over the filtered rows -- goes to HBM first, as whole rows.  Two more
+        // iterations drain the last two chunks.
+        for (int ch = 0; ch < nch + 2; ++ch) {
+            const int buf = ch & 1, n_hi = n_top - ch * FZ_C;
+#pragma unroll
+            for (int s0 = 0; s0 < FZ_C; s0 += NPROD) {
+                const int sl = s0 + pw, n = n_hi - sl, n_old = n + 2 * FZ_C;
+                double* const til = sh + TIL + (buf * FZ_C + sl) * TW;
+                double* const rec = sh + REC + (buf * FZ_C + sl) * RW;
+                if (ch >= 2 && n_old >= n_bot) {           // (uniform)
+                    const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)n_old * tstride, tbytes);
+                    const u32x4* const src = (const u32x4*)til;
+#pragma unroll
+                    for (int i = 0; i < NLT; ++i) __builtin_amdgcn_raw_buffer_store_b128(src[64 * i + lane], t, 1024 * i + 16 * lane, 0, 0);
+                }
+                if (ch < nch && n >= n_bot) {              // (uniform)
+                    u32x4* const dst = (u32x4*)til;
+#pragma unroll
+                    for (int i = 0; i < NLT; ++i) dst[64 * i + lane] = row[i];
+                    double v[P], mu;
+#pragma unroll
+                    for (int k = 0; k < P; ++k) v[k] = til[iV[k]];
+                    mu = til[iMu];
+                    if (n - NPROD >= n_bot) gload(n - NPROD);
+                    double A[P], Sp[P], mp;
+#ifdef RK_FZ_NOPROD       // experiment build: the producers only move data (wrong results; the chain wave's own speed)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) { A[i] = v[i]; Sp[i] = v[i]; }
+                    mp = mu;
+#else
+                    cols_gain_item<P>(Qc, Qr, Rc, h, v, mu, A, Sp, mp);
+#endif
+#pragma unroll
+                    for (int i = 0; i < P; ++i) rec[iOut[i]] = h ? A[i] : Sp[i];
+                    rec[iMp] = mp;
+                    if constexpr (RS != RS0) rec[iPad] = 0.0;
+                }
+            }
+            lap(t_work);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            lap(t_wait);
+        }
+        if (dbg && blockIdx.x == 0 && lane == 0) { dbg[2 * wave] = (double)t_work; dbg[2 * wave + 1] = (double)t_wait; }
+        return;
+    }
+    // ================= wave 0: the chain (bwd_mv_tilen_kernel's step, operands out of LDS) =================
+    // (the chain is the serial part: it goes first wherever it shares a SIMD with producer waves)
+    __builtin_amdgcn_s_setprio(3);
+    const int r = lane >> 4, g = (lane >> 2) & 3, c = lane & 3;
+    const bool valid = g < n_valid;
+    // l*: where this lane's tile elements sit in a record / tile slot (padding lanes: the slots' zero words).  The smoothed
+    // tiles go back INTO the tile slot: w* = index in slot 0 + slot * ws* (padding lanes of real units write their exact
+    // zeros onto the zero word; lanes of units past the end write into their own unused part of the row; the copies of a mean
+    // entry in the columns c > 0 go to the record slot's dump word).
+    int lG[NB][NB], lP[NB][NB], lS[NB][NB], lMp[NB], lMf[NB], oS[NB][NB], oM[NB], wS[NB][NB], wM[NB], wsM[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int i = 4 * k + r;
+        const bool iv = i < P;
+        lMp[k] = iv ? g * RS + 2 * P * P + i : 4 * RS + 1;
+        lMf[k] = iv ? g * PP + P * P + i : TW - 1;
+        oM[k] = (valid && iv) ? (g * PP + P * P + i) * 8 : TN_OOR;
+        const bool wm = valid && iv && c == 0;
+        wM[k] = wm ? TIL + g * PP + P * P + i : REC + 4 * RS;
+        wsM[k] = wm ? TW : RW;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+            const int jc = 4 * bb + c;
+            const bool in = iv && jc < P;
+            lG[k][bb] = in ? g * RS + i * P + jc : 4 * RS + 1;
+            lP[k][bb] = in ? g * RS + P * P + i * P + jc : 4 * RS + 1;
+            lS[k][bb] = in ? g * PP + i * P + jc : TW - 1;
+            oS[k][bb] = (valid && in) ? (g * PP + i * P + jc) * 8 : TN_OOR;
+            wS[k][bb] = TIL + (valid ? (in ? g * PP + i * P + jc : TW - 1) : g * PP);
+        }
+    }
+    double Ms[NB][NB], ms[NB];
+    {
+        const __amdgpu_buffer_rsrc_t t = buf_window(tw + (size_t)(n_top + 1) * tstride, tbytes);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            ms[k] = buf_ld(t, oM[k]);
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) Ms[k][bb] = buf_ld(t, oS[k][bb]);
+        }
+    }
+    // What the step costs is latency, not work (s_memtime stamps of the first version: 1074 cycles per step at p = 5 with the
+    // producers idle, for 20 MFMAs = 320 cycles of issue): (i) the record of step n - 1 is read out of LDS into registers
+    // BEFORE the arithmetic of step n (inside a chunk); (ii) the smoothed tiles go back into the LDS tile slot and leave from
+    // there in the producers' hands -- with its own global stores the chain waited (vmcnt) every step until the previous
+    // step's stores had read their data, 520 of the 1080 cycles (copies of the stored values in other registers did not help); (iii) the chunk barrier waits for LDS
+    // only (fz_barrier): nobody in this kernel reads the stores.
+    struct Rec { double Gt[NB][NB], Sp[NB][NB], Sf[NB][NB], mp[NB], mf[NB]; };
+    auto lds_load = [&](Rec& q, const double* rec, const double* til) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            q.mp[k] = rec[lMp[k]];
+            q.mf[k] = til[lMf[k]];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                q.Gt[k][bb] = rec[lG[k][bb]];
+                q.Sp[k][bb] = rec[lP[k][bb]];
+                q.Sf[k][bb] = til[lS[k][bb]];
+            }
+        }
+    };
+    auto step = [&](const Rec& q, int slot) {
+        double Dm[NB][NB], dm[NB], V1[NB][NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            dm[k] = ms[k] - q.mp[k];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) Dm[k][bb] = Ms[k][bb] - q.Sp[k][bb];
+        }
+        bmm_tn0<NB>(Dm, q.Gt, V1);                        // (G D)^T
+        bmm_tn<NB>(V1, q.Gt, q.Sf, Ms);                   // G D G^T + Sigma_f      (standard.py:215-216)
+        bmv_t<NB>(q.Gt, dm, q.mf, ms);                    // G (m_s - m-) + mu_f    (standard.py:213-214)
+#ifndef RK_FZ_NOSTORE      // (experiment build without the hand-over: what it costs the chain)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            sh[wM[k] + slot * wsM[k]] = ms[k];
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) sh[wS[k][bb] + slot * TW] = Ms[k][bb];
+        }
+#endif
+    };
+    auto fz_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    for (int ch0 = 0; ch0 < nch; ch0 += 2) {
+#pragma unroll
+        for (int buf = 0; buf < 2; ++buf) {
+            const int ch = ch0 + buf;
+            if (ch < nch) {                                // (uniform)
+                lap(t_work);
+                fz_barrier();
+                lap(t_wait);
+                const int n_hi = n_top - ch * FZ_C;
+                Rec q[2];
+                lds_load(q[0], sh + REC + (buf * FZ_C) * RW, sh + TIL + (buf * FZ_C) * TW);
+#pragma unroll
+                for (int sl = 0; sl < FZ_C; ++sl) {
+                    if (n_hi - sl >= n_bot) {
+                        if (sl + 1 < FZ_C)                 // (slots past n_bot hold stale records: loaded, never used)
+                            lds_load(q[(sl + 1) & 1], sh + REC + (buf * FZ_C + sl + 1) * RW, sh + TIL + (buf * FZ_C + sl + 1) * TW);
+                        step(q[sl & 1], buf * FZ_C + sl);
+                    }
+                }
+            }
+        }
+    }
+    fz_barrier();                                          // (the producers' two draining iterations)
+    fz_barrier();
+    lap(t_work);
+    if (dbg && blockIdx.x == 0 && lane == 0) { dbg[0] = (double)t_work; dbg[1] = (double)t_wait; }
+}
+
 template <int NB>
 __global__ void __launch_bounds__(64) bwd_sim_tilen_kernel(SolveArgs a, const double* __restrict__ tiles, const double* __restrict__ ws, int P) {
     const int D = a.D, n_units = a.B * D, PP = P * P + P, RS = tilen_rs(P, true);
@@ -819,6 +1046,27 @@ int tilen_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     // workgroups take every free slot and the two kernels mostly alternate.  A fused producer / consumer workgroup like the
     // p = 3 kernels: 2.76 ms at n_deriv = 5, 5.1 ms at 6 -- its producers need > 256 VGPRs, so one workgroup per CU and
     // two rounds; capped at 256 VGPRs they spill: 4.9 ms.  Both removed.)
+    // One kernel (bwd_mv_tilen_fused_kernel) at n_bstate >= 5; RK_TILEN_BWD = split selects the two-kernel form below (kept as the
+    // parity test's other leg and for n_bstate = 4 with interrogate_chkrebtii, whose solve_mv has no hand-trimmed kernel).
+    const char* const bforce = getenv("RK_TILEN_BWD");
+    if (P >= 5 && !(bforce && bforce[0] == 's')) {
+        // producer waves per chain wave: RK_TILEN_PROD = 2 | 4 (measured below)
+        const char* const pforce = getenv("RK_TILEN_PROD");
+        const int nprod = pforce ? atoi(pforce) : 4;
+        double* const dbg = getenv("RK_TILEN_STAMPS") ? ws : nullptr;        // (the two-kernel form's workspace is free here)
+        const dim3 fgrid(div_up(n_units, 4)), fblock(64 * (1 + (nprod == 2 ? 2 : 4)));
+        LaunchTimer t(h, "bwd_mv_tilen_fused_kernel");
+#define RK_FUSED(P_)                                                                                                         \
+    case P_:                                                                                                                 \
+        if (nprod == 2) hipLaunchKernelGGL((bwd_mv_tilen_fused_kernel<P_, 2>), fgrid, fblock, 0, h->stream, a, tiles, a.N - 1, 1, dbg);   \
+        else hipLaunchKernelGGL((bwd_mv_tilen_fused_kernel<P_, 4>), fgrid, fblock, 0, h->stream, a, tiles, a.N - 1, 1, dbg);      \
+        break;
+        switch (P) { RK_FUSED(5) RK_FUSED(6) RK_FUSED(7) RK_FUSED(8) }
+#undef RK_FUSED
+        t.stop();
+        RK_HIP(hipGetLastError());
+        return RK_OK;
+    }
     // phase 1 of solve_mv: one 16-lane row per item (tilen_gain_cols_kernel).  Measured, headline shape, ms at n_bstate = 5 .. 8:
     // one lane per item 1.27 / 2.20 / 4.32 / 9.00, rows of lanes 1.18 / 1.71 / 2.33 / 2.64 (profiles/r03_nderiv_times_v2.jsonl);
     // RK_TILEN_GAIN = lanes | cols overrides the choice (both forms give the same bits: tests/test_gpu_tilen.py)

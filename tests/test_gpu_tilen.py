@@ -222,7 +222,7 @@ def test_blocked_tiles_chain_variants_agree(ra):
         "print(json.dumps(out))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for form in ("rows", "scattered"):
-        env = dict(os.environ, RK_TILEN_CHAIN=form)
+        env = dict(os.environ, RK_TILEN_CHAIN=form, RK_TILEN_BWD="split")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[form] = json.loads(r.stdout.strip().splitlines()[-1])
@@ -230,18 +230,24 @@ def test_blocked_tiles_chain_variants_agree(ra):
 
 
 @pytest.mark.parametrize("p", [4, 5, 6, 7, 8])
-@pytest.mark.parametrize("B,N", [(5, 37), (1, 70), (2, 2)])
+@pytest.mark.parametrize("B,N", [(5, 37), (1, 70), (2, 2), (3, 6), (2, 9)])
 def test_blocked_tiles_gain_variants_agree(ra, p, B, N, monkeypatch):
-    """The two forms of the time-parallel gain items of solve_mv (one lane per item; one 16-lane DPP row per item with a
-    matrix column per lane, rodeo_amd/csrc/solve_tilen.hip tilen_gain_cols_kernel) sum the same terms in the same order:
-    the smoothed means and variances are the same to the bit, at ragged unit counts (10 units = 2.5 waves) and across
-    the 32-step chunks of the column form.  RK_TILEN_GAIN is read per call."""
+    """Three forms of solve_mv's backward pass on the blocked tiles (rodeo_amd/csrc/solve_tilen.hip) sum the same terms in the
+    same order -- the smoothed means and variances are the same to the bit, at ragged unit counts (10 units = 2.5 waves),
+    across the 32-step chunks of the column-per-lane gain kernel and the 4-step chunks of the fused kernel:
+      split + lanes : tilen_gain_kernel (one lane per item)   + the chain kernel, records through HBM
+      split + cols  : tilen_gain_cols_kernel (a 16-lane DPP row per item, a matrix column per lane) + the chain kernel
+      fused         : bwd_mv_tilen_fused_kernel (the chain wave fed through LDS by two gain waves; the default at n_bstate >= 5)
+    RK_TILEN_BWD / RK_TILEN_GAIN are read per call."""
     s = _fitz(ra, p, B=B, N=N, t_max=0.01 * N)
     plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, s["W"], s["x0"], 0.0, s["t_max"], s["N"], ra.interrogate.interrogate_kramer,
                         s["prior"], theta=s["theta"])
     res = {}
-    for form in ("lanes", "cols"):
-        monkeypatch.setenv("RK_TILEN_GAIN", form)
+    for form, env in (("lanes", dict(RK_TILEN_BWD="split", RK_TILEN_GAIN="lanes")),
+                      ("cols", dict(RK_TILEN_BWD="split", RK_TILEN_GAIN="cols")), ("fused", dict(RK_TILEN_BWD="fused"))):
+        monkeypatch.delenv("RK_TILEN_GAIN", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         plan.dev.profile_enable(True)
         plan.mv(None)
         m, v = plan.state_host()
@@ -249,10 +255,12 @@ def test_blocked_tiles_gain_variants_agree(ra, p, B, N, monkeypatch):
         plan.dev.profile_enable(False)
         if N >= 2 and p >= 5:                            # (p = 4 solve_mv: the hand-trimmed kernels of solve_tile4.hip)
             assert ("tilen_gain_cols_kernel" in names) == (form == "cols"), names
+            assert ("bwd_mv_tilen_fused_kernel" in names) == (form == "fused"), names
         res[form] = (np.array(m), np.array(v))
-    assert np.all(np.isfinite(res["cols"][0])) and np.all(np.isfinite(res["cols"][1]))
-    np.testing.assert_array_equal(res["lanes"][0], res["cols"][0])
-    np.testing.assert_array_equal(res["lanes"][1], res["cols"][1])
+    assert np.all(np.isfinite(res["fused"][0])) and np.all(np.isfinite(res["fused"][1]))
+    for form in ("cols", "fused"):
+        np.testing.assert_array_equal(res["lanes"][0], res[form][0])
+        np.testing.assert_array_equal(res["lanes"][1], res[form][1])
 
 
 @pytest.mark.parametrize("p,rhs", [(5, "lorenz63"), (6, "lorenz63"), (6, "higher_order"), (8, "higher_order")])
