@@ -109,6 +109,40 @@ __global__ void __launch_bounds__(64) bwd_sqrt_kernel(SolveArgs a) {
     }
 }
 
+// RK_FLAG_STORE_PRED (_solve_filter's "state_pred" in square-root form): the predicted means and FACTORS are a function of the
+// filtered ones and the prior alone, pred[n + 1] = sqrt_predict(filt[n]) (square_root.py:56-57), so they are re-evaluated for
+// all time steps at once behind the forward pass -- the same arithmetic as inside it, one lane per (time, block, trajectory);
+// a store inside the time loop cost the filter 8 % whether or not it was taken.  Index 0 = (ode_init, 0) (solve.py:114-121).
+template <int P>
+__global__ void __launch_bounds__(64) sqrt_pred_kernel(SolveArgs a) {
+    const size_t B = (size_t)a.B, per_step = (size_t)a.D * B;
+    const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= (size_t)(a.N + 1) * per_step) return;
+    const int n = (int)(l / per_step), blk = (int)((l - (size_t)n * per_step) / B), b = (int)(l % B);
+    double mup[P], Lp[P][P];
+    if (n == 0) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            mup[i] = a.mean[((size_t)blk * P + i) * B + b];
+#pragma unroll
+            for (int j = 0; j < P; ++j) Lp[i][j] = 0.0;
+        }
+    } else {
+        double Q[P][P], LR[P][P], mf[P], Lf[P][P];
+        load_block_consts<P>(a, blk, b, Q, LR);
+        load_state<P>(a, n - 1, blk, b, mf, Lf);
+        sqrt_predict<P>(Q, LR, mf, Lf, mup, Lp);
+    }
+    double* mpo = a.mean_pred + ((size_t)n * a.D + blk) * P * B + b;
+    double* vpo = a.var_pred + ((size_t)n * a.D + blk) * P * P * B + b;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        mpo[(size_t)i * B] = mup[i];
+#pragma unroll
+        for (int j = 0; j < P; ++j) vpo[((size_t)i * P + j) * B] = Lp[i][j];
+    }
+}
+
 template <class RHS, int P>
 static int launch_fwd_sqrt_p(rk_handle h, const SolveArgs& a, int itg) {
     const dim3 grid(div_up(a.B, 64)), block(64);
@@ -148,8 +182,7 @@ int user_forward_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a);
 int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a_, int mode) {
     RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 8, RK_ERR_UNSUPPORTED, "square-root solver supports n_bstate in [2, 8], got %d",
                c->n_bstate);
-    SolveArgs a = a_;
-    if (!(c->flags & RK_FLAG_STORE_PRED)) a.mean_pred = a.var_pred = nullptr;       // (the kernel stores predictions iff both are set)
+    const SolveArgs& a = a_;
     int rc;
     if (is_user_rhs(c->rhs_id)) rc = user_forward_sqrt(h, c, a);      // hiprtc build of fwd_sqrt_kernel (rhs_jit.hip)
     else switch (c->rhs_id) {
@@ -158,7 +191,19 @@ int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a_, int mode
         case RK_RHS_HIGHER_ORDER: rc = launch_fwd_sqrt<HigherOrder>(h, c, a); break;
         default: set_error("unknown rhs_id %d for the square-root solver", c->rhs_id); return RK_ERR_UNSUPPORTED;
     }
-    if (rc || mode == RK_MODE_FILTER) return rc;
+    if (rc) return rc;
+    if (c->flags & RK_FLAG_STORE_PRED) {
+        const size_t lanes = (size_t)(a.N + 1) * a.D * (size_t)a.B;
+        RK_REQUIRE(lanes < 0x7fffffffull * 64, RK_ERR_UNSUPPORTED, "square-root solver: too many (time, block, trajectory) items for one launch");
+        const dim3 pgrid((unsigned)((lanes + 63) / 64)), pblock(64);
+        LaunchTimer t(h, "sqrt_pred_kernel");
+#define RK_SQP(P_) case P_: hipLaunchKernelGGL((sqrt_pred_kernel<P_>), pgrid, pblock, 0, h->stream, a); break;
+        switch (c->n_bstate) { RK_SQP(2) RK_SQP(3) RK_SQP(4) RK_SQP(5) RK_SQP(6) RK_SQP(7) RK_SQP(8) }
+#undef RK_SQP
+        t.stop();
+        RK_HIP(hipGetLastError());
+    }
+    if (mode == RK_MODE_FILTER) return RK_OK;
     const dim3 grid(div_up(a.B * a.D, 64)), block(64);
     LaunchTimer t(h, mode == RK_MODE_SIM ? "bwd_sqrt_sim_kernel" : "bwd_sqrt_mv_kernel");
 #define RK_SQ(P_)                                                                                        \

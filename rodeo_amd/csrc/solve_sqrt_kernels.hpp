@@ -10,12 +10,9 @@
 
 namespace rk {
 
-// a.mean_pred / a.var_pred non-null (RK_FLAG_STORE_PRED, _solve_filter's "state_pred"): the predicted means and FACTORS go
-// there, batch-minor like the filtered ones (index 0 = (ode_init, 0), solve.py:114-121).
 template <class RHS, int P, int ITG>
 __global__ void __launch_bounds__(64) fwd_sqrt_kernel(SolveArgs a) {
     constexpr int D = RHS::D;
-    const bool store_pred = a.mean_pred != nullptr && a.var_pred != nullptr;
     constexpr int KV = ITG == RK_INTERROGATE_CHKREBTII ? P : 1;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
@@ -31,12 +28,10 @@ __global__ void __launch_bounds__(64) fwd_sqrt_kernel(SolveArgs a) {
             W[blk][i] = ld(a.W, em, a.W_b, a.B, b);
             mu[blk][i] = ld(a.x0, em, a.x0_b, a.B, b);
             a.mean[em * B + b] = mu[blk][i];
-            if (store_pred) a.mean_pred[em * B + b] = mu[blk][i];
 #pragma unroll
             for (int j = 0; j < P; ++j) {
                 L[blk][i][j] = 0.0;
                 a.var[(em * P + j) * B + b] = 0.0;
-                if (store_pred) a.var_pred[(em * P + j) * B + b] = 0.0;
             }
         }
     const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
@@ -48,17 +43,6 @@ __global__ void __launch_bounds__(64) fwd_sqrt_kernel(SolveArgs a) {
             double Q[P][P], LR[P][P];
             load_block_consts<P>(a, blk, b, Q, LR);
             sqrt_predict<P>(Q, LR, mu[blk], L[blk], mup[blk], Lp[blk]);                  // square_root.py:56-57
-            if (store_pred) {
-                double* mpo = a.mean_pred + (size_t)(n + 1) * mstride + b;
-                double* vpo = a.var_pred + (size_t)(n + 1) * vstride + b;
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    const size_t em = (size_t)blk * P + i;
-                    mpo[em * B] = mup[blk][i];
-#pragma unroll
-                    for (int j = 0; j < P; ++j) vpo[(em * P + j) * B] = Lp[blk][i][j];
-                }
-            }
         }
         const double t = a.t_min + (a.t_max - a.t_min) * (double)(n + 1) / (double)a.N;  // solve.py:74
         // ---- interrogation (interrogate.py) with the factor standing where the reference puts it ----

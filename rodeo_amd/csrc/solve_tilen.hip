@@ -626,14 +626,23 @@ bwd_mv_tilen_rows_kernel(SolveArgs a, double* __restrict__ tiles, const double* 
     }
 }
 
-// ---- solve_mv backward pass in ONE kernel: the chain wave fed through LDS by two gain waves ------------------------------------
+// ---- solve_mv backward pass in ONE kernel: the chain wave fed through LDS by gain waves -----------------------------------------
 // The two-kernel form writes a record of 2 p^2 + p doubles per (step, unit) to HBM and reads it back (3.4 x the backward pass's
 // algorithmic traffic, profiles/r03_nderiv5_pmc_traffic.json), and its chain spends most of its step on the 16 scattered loads
-// that fetch the record.  Here a workgroup is four units: wave 0 runs the chain of bwd_mv_tilen_kernel, waves 1 and 2 produce
-// the records of the next chunk of FZ_C time steps (cols_gain_item: a 16-lane row per unit, alternate steps) straight into
+// that fetch the record and on waiting for its own stores.  Here a workgroup is four units: wave 0 runs the chain of
+// bwd_mv_tilen_kernel, waves 1 .. NPROD produce the records of the next chunk of FZ_C time steps (cols_gain_item: a 16-lane row
+// per unit, every NPROD-th step) straight into
 // LDS, double-buffered, one barrier per chunk; the filtered tiles they load as whole rows stay in LDS for the chain too, so
-// the chain's only memory instructions are LDS reads and the stores of the smoothed tiles.  HBM sees the filtered tiles once
-// and the smoothed tiles once.  The producers run ahead of the chain (lower n), so the in-place stores never meet a load.
+// the chain's only memory instructions are LDS accesses: it writes the smoothed tiles over the filtered rows in their LDS slot
+// and the producers store them as whole rows before they refill the slot.  HBM sees the filtered tiles once and the smoothed
+// tiles once.  The producers run ahead of the chain (lower n), so the in-place stores never meet a load.
+// Where the time goes (s_memtime stamps per wave, RK_TILEN_STAMPS=1, scripts/probe/fz_stamps.py; cycles per step at p = 5 / 8):
+// chain 594 / 648 of work + 312 / 781 at the barriers, producers 600-880 / 1110-1400 per step, i.e. 2400-3500 / 4500-5600
+// per item (four items per producer and four steps): the workgroup's ten waves per CU are VALU-issue-bound on the gain
+// items -- (2 x 1800 + 2 x 594) / 4 SIMDs = 1200 cycles per step at p = 5 is what is measured.  Tried and removed: a ring of
+// eight slots with an LDS item counter and ready / consumed flags instead of the chunk barrier (the waves of a workgroup
+// share SIMDs unevenly and the slowest producer sets the pace of a chunk): 2.45 / 2.90 / 4.28 / 4.70 ms at p = 5 .. 8
+// against 2.32 / 2.77 / 3.35 / 4.80 -- the flags and run-time slot addresses cost the chain what the balance gains.
 constexpr int FZ_C = 4;                                   // time steps per chunk
 
 template <int P, int NPROD>

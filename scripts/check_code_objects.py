@@ -27,7 +27,7 @@ SCRATCH_ALLOW = {"kalman_op_kernel": 32768,        # kalman_batched.hip: runtime
                  "13bwd_mv_kernel": 6144,          # solve_small.hip, one lane per (trajectory, block): the p x p register matrices
                  "14bwd_sim_kernel": 6144,         # spill from n_bstate = 7 on (the n_bmeas > 1 / non-block path, p <= 9)
                  "10fwd_kernelINS_8Lorenz63ELi6": 4096,   # lane-per-trajectory forward, three blocks of 6 x 6 per lane (fenrir / _solve_filter at p = 6)
-                 "15fwd_sqrt_kernel": 8192,       # solve_sqrt.hip, lane-per-trajectory square-root filter: the stacked (2p x p)
+                 "15fwd_sqrt_kernel": 6144,       # solve_sqrt.hip, lane-per-trajectory square-root filter: the stacked (2p x p)
                  "15bwd_sqrt_kernel": 6144}       # Householder inputs of every block spill from n_bstate = 7 on (functional path)
 LDS_LIMIT = 160 * 1024
 FIELDS = ("agpr_count", "group_segment_fixed_size", "max_flat_workgroup_size", "private_segment_fixed_size",
