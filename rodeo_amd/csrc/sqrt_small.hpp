@@ -27,11 +27,13 @@ __device__ __forceinline__ void add_sqrt(const double (&A)[P][KA], const double 
             double tail2 = 0.0;
 #pragma unroll
             for (int i = c + 1; i < R; ++i) tail2 = fma(S[i][c], S[i][c], tail2);
-            const double nrm = sqrt(fma(S[c][c], S[c][c], tail2));
+            const double nrm = fast_sqrt_pos(fma(S[c][c], S[c][c], tail2));      // (<= 1 ulp, linalg_small.hpp: the Householder
+                                                                                  //  columns are one dependent chain, sqrt() + a
+                                                                                  //  division were 45 of its ~60 instructions)
             const double alpha = S[c][c] >= 0.0 ? -nrm : nrm;
             const double v0 = S[c][c] - alpha;
             const double vn2 = fma(v0, v0, tail2);
-            const double tau = vn2 != 0.0 ? 2.0 / vn2 : 0.0;          // all-zero column: no reflection
+            const double tau = vn2 != 0.0 ? 2.0 * fast_rcp(vn2) : 0.0;     // all-zero column: no reflection
 #pragma unroll
             for (int j = c + 1; j < P; ++j) {
                 double d = v0 * S[c][j];
@@ -51,9 +53,13 @@ __device__ __forceinline__ void add_sqrt(const double (&A)[P][KA], const double 
         for (int j = 0; j < P; ++j) F[i][j] = (j <= i && j < R) ? S[j][i] : 0.0;
 }
 
-// L X = B (L lower P x P), B (P x NR) overwritten
+// L X = B (L lower P x P), B (P x NR) overwritten.  The P reciprocals of the diagonal (fast_rcp, <= 1 ulp) are formed once
+// instead of P NR divisions.
 template <int P, int NR>
 __device__ __forceinline__ void solve_lower(const double (&L)[P][P], double (&B)[P][NR]) {
+    double rd[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) rd[i] = fast_rcp(L[i][i]);
 #pragma unroll
     for (int j = 0; j < NR; ++j)
 #pragma unroll
@@ -61,12 +67,15 @@ __device__ __forceinline__ void solve_lower(const double (&L)[P][P], double (&B)
             double s = B[i][j];
 #pragma unroll
             for (int l = 0; l < i; ++l) s = fma(-L[i][l], B[l][j], s);
-            B[i][j] = s / L[i][i];
+            B[i][j] = s * rd[i];
         }
 }
 // L^T X = B
 template <int P, int NR>
 __device__ __forceinline__ void solve_upper_t(const double (&L)[P][P], double (&B)[P][NR]) {
+    double rd[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) rd[i] = fast_rcp(L[i][i]);
 #pragma unroll
     for (int j = 0; j < NR; ++j)
 #pragma unroll
@@ -74,7 +83,7 @@ __device__ __forceinline__ void solve_upper_t(const double (&L)[P][P], double (&
             double s = B[i][j];
 #pragma unroll
             for (int l = i + 1; l < P; ++l) s = fma(-L[l][i], B[l][j], s);
-            B[i][j] = s / L[i][i];
+            B[i][j] = s * rd[i];
         }
 }
 
@@ -107,10 +116,11 @@ __device__ __forceinline__ void sqrt_update_m1(const double (&W)[P], double a, c
     for (int j = 0; j < P; ++j) s2 = fma(wl[j], wl[j], s2);
 #pragma unroll
     for (int k = 0; k < KV; ++k) s2 = fma(vm[k], vm[k], s2);
-    const double sfac = sqrt(s2);                       // |add_sqrt(W L, vm)| (1 x 1)
+    const double sfac = fast_sqrt_pos(s2);              // |add_sqrt(W L, vm)| (1 x 1)
+    const double rsf = fast_rcp(sfac);                  // (one reciprocal for the 2 P divisions by it)
     double t1[P], t2[P], t3[P], K[P];
 #pragma unroll
-    for (int j = 0; j < P; ++j) t1[j] = W[j] / sfac;    // solve_triangular(s, W)
+    for (int j = 0; j < P; ++j) t1[j] = W[j] * rsf;     // solve_triangular(s, W)
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         double s = t1[0] * Lp[0][j];
@@ -121,7 +131,7 @@ __device__ __forceinline__ void sqrt_update_m1(const double (&W)[P], double a, c
 #pragma unroll
     for (int i = 0; i < P; ++i) t3[i] = dot<P>(t2, Lp[i]);
 #pragma unroll
-    for (int i = 0; i < P; ++i) K[i] = t3[i] / sfac;    // solve_triangular(s^T, .)^T
+    for (int i = 0; i < P; ++i) K[i] = t3[i] * rsf;     // solve_triangular(s^T, .)^T
     const double innov = 0.0 - yhat;
     double KW[P][P], KWL[P][P], A1[P][P], B1[P][KV];
 #pragma unroll
