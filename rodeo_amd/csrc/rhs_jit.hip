@@ -220,7 +220,7 @@ int user_forward_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a) {
     SolveArgs args = a;
     void* params[] = {&args};
     LaunchTimer t(h, "fwd_sqrt_kernel<user>");
-    RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B, 64), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));
+    RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B, 64 / c->n_block), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));     // 64 / D trajectories per wave
     t.stop();
     return RK_OK;
 }

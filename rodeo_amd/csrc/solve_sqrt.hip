@@ -3,7 +3,8 @@
 // square-root factor and add_sqrt (Householder QR, src/rodeo/utils.py:10-24) in place of the variance sums.
 //   prior_pars = (Q, chol(R))  as in docs/examples/higher_order.md:106-125
 //   outputs: mean (N+1, d, p, B) and the FACTORS (N+1, d, p, p, B), batch-minor, like the reference's return values.
-// One lane per trajectory forward (the interrogation couples the blocks), one lane per (block, trajectory) backward.
+// One lane per (trajectory, block), forward (the blocks of a trajectory in neighbouring lanes: the interrogation couples them)
+// and backward.
 // Reference quirks kept because they define the reference's numbers in this mode (oracle/interrogations.py has the
 // same): interrogate_rodeo hands W L- W^T and interrogate_chkrebtii hands W L- (1 x p) to the update as the
 // "factor" of var_meas (src/rodeo/interrogate.py:36-42, 110-113).  One quirk is NOT kept: solve_sim's draws use
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(64) sqrt_pred_kernel(SolveArgs a) {
 
 template <class RHS, int P>
 static int launch_fwd_sqrt_p(rk_handle h, const SolveArgs& a, int itg) {
-    const dim3 grid(div_up(a.B, 64)), block(64);
+    const dim3 grid(div_up(a.B, 64 / RHS::D)), block(64);      // 64 / D trajectories per wave (solve_sqrt_kernels.hpp)
     LaunchTimer t(h, "fwd_sqrt_kernel");
     switch (itg) {
         case RK_INTERROGATE_RODEO: hipLaunchKernelGGL((fwd_sqrt_kernel<RHS, P, RK_INTERROGATE_RODEO>), grid, block, 0, h->stream, a); break;
