@@ -549,7 +549,8 @@ int user_interrogate(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, dou
                      const double* vp, double* wm, double* mm_, double* vm);
 
 // fused square-root solver (solve_sqrt.hip)
-int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode);
+int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, int mode, double* ws, size_t ws_bytes);
+size_t sqrt_ws_doubles(const rk_solve_cfg* c, int mode);
 
 // fenrir with kalman_type = square-root (fenrir_sqrt.hip)
 size_t fenrir_sqrt_item_doubles(int p);
@@ -592,6 +593,7 @@ int rk_solve_layout(const rk_solve_cfg* c, int32_t mode, int32_t* layout) {
 int rk_solve_workspace_bytes(const rk_solve_cfg* c, int32_t mode, size_t* bytes) {
     RK_REQUIRE(c && bytes, RK_ERR_INVALID, "rk_solve_workspace_bytes: null argument");
     if (dense_supported(c, mode)) *bytes = dense_ws_bytes(c, mode);
+    else if (c->kalman_type == RK_KALMAN_SQRT) *bytes = sqrt_ws_doubles(c, mode) * sizeof(double);     // optional (solve_sqrt.hip)
     else if (!tile3_supported(c, mode) && !tile4_supported(c, mode) && tilen_supported(c, mode))
         *bytes = tilen_ws_doubles(c, mode) * sizeof(double);
     else *bytes = 0;
@@ -654,7 +656,7 @@ static int solve_common(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* i
     if (!h->profile_keep) { h->prof.clear(); h->event_used = 0; }
     SolveArgs a;
     make_args(c, in, out, a);
-    if (c->kalman_type == RK_KALMAN_SQRT) return sqrt_solve(h, c, a, mode);
+    if (c->kalman_type == RK_KALMAN_SQRT) return sqrt_solve(h, c, a, mode, (double*)out->workspace, out->workspace_bytes);
     if (tile4) return tile4_solve(h, c, a, out->var_state, mode);
     if (tile3) return tile3_solve(h, c, a, out->var_state, mode);
     if (tilen) return tilen_solve(h, c, a, out->var_state, (double*)out->workspace, out->workspace_bytes, mode);

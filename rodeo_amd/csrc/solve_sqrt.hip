@@ -110,6 +110,116 @@ __global__ void __launch_bounds__(64) bwd_sqrt_kernel(SolveArgs a) {
     }
 }
 
+// ---- solve_mv backward pass in two kernels (the blocked tile path's split, solve_tilen.hip) -------------------------------------
+// Everything of a smoothing step that does not depend on the carry -- the re-evaluated prediction (a Householder QR), the gain
+// G (two triangular solves), J L_f = (I - G Q) L_f and G R^{1/2} (square_root.py:170-175, 214-217) -- is evaluated for ALL time
+// steps at once, one lane per (step, block, trajectory), into a batch-minor workspace record [G | J L_f | G R^{1/2} | mu-] of
+// 3 p^2 + p doubles; the sequential part that remains per step is G L_s, one add_sqrt (the QR of the 3 p x p stack) and the
+// mean: ~250 instead of ~850 instructions on the one-lane-per-block chain whose length is the run time at small batches
+// (7.3 -> 2.x ms at n_deriv = 3 on the headline shape).  Same arithmetic in the same order as bwd_sqrt_kernel<P, false>, which
+// stays as the path without a workspace.
+__host__ __device__ inline size_t sqrt_rec_doubles(int p) { return 3 * (size_t)p * p + p; }
+
+template <int P>
+__global__ void __launch_bounds__(64) sqrt_gain_kernel(SolveArgs a, double* __restrict__ ws) {
+    const size_t B = (size_t)a.B, per_step = (size_t)a.D * B;
+    const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= (size_t)(a.N - 1) * per_step) return;
+    const int n = 1 + (int)(l / per_step), blk = (int)((l % per_step) / B), b = (int)(l % B);
+    double Q[P][P], LR[P][P], mf[P], Lf[P][P], mp[P], Lp[P][P], G[P][P], JL[P][P], GR[P][P];
+    load_block_consts<P>(a, blk, b, Q, LR);
+    load_state<P>(a, n, blk, b, mf, Lf);
+    sqrt_predict<P>(Q, LR, mf, Lf, mp, Lp);                      // pred[n+1] re-evaluated from filt[n]
+    sqrt_gain<P>(Q, Lf, Lp, G, JL);
+    mm<P, P, P>(G, LR, GR);
+    double* rec = ws + ((size_t)n * a.D + blk) * sqrt_rec_doubles(P) * B + b;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        rec[(size_t)(3 * P * P + i) * B] = mp[i];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            rec[(size_t)(i * P + j) * B] = G[i][j];
+            rec[(size_t)(P * P + i * P + j) * B] = JL[i][j];
+            rec[(size_t)(2 * P * P + i * P + j) * B] = GR[i][j];
+        }
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(64) bwd_sqrt_chain_kernel(SolveArgs a, const double* __restrict__ ws) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.B * a.D) return;
+    const int blk = l / a.B, b = l - blk * a.B;
+    const size_t B = (size_t)a.B;
+    double ms[P], Ls[P][P];
+    load_state<P>(a, a.N, blk, b, ms, Ls);                       // carry = filt[N]
+    struct Rec { double G[P][P], JL[P][P], GR[P][P], mp[P], mf[P]; };
+    auto load = [&](int n, Rec& q) {
+        const double* rec = ws + ((size_t)n * a.D + blk) * sqrt_rec_doubles(P) * B + b;
+        const double* mi = a.mean + ((size_t)n * a.D + blk) * P * B + b;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            q.mp[i] = rec[(size_t)(3 * P * P + i) * B];
+            q.mf[i] = mi[(size_t)i * B];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                q.G[i][j] = rec[(size_t)(i * P + j) * B];
+                q.JL[i][j] = rec[(size_t)(P * P + i * P + j) * B];
+                q.GR[i][j] = rec[(size_t)(2 * P * P + i * P + j) * B];
+            }
+        }
+    };
+    // RD records in flight (static register names in an unrolled ring): a record comes from HBM / the memory-side cache, two
+    // or three chain steps away at p = 3
+    constexpr int RD = P <= 3 ? 4 : (P == 4 ? 3 : 2);
+    Rec q[RD];
+#pragma unroll
+    for (int s = 0; s < RD; ++s) load(a.N - 1 - s >= 1 ? a.N - 1 - s : 1, q[s]);
+    auto step = [&](int n, Rec& r) {
+        double dm[P], gm[P], GA[P][2 * P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) dm[i] = ms[i] - r.mp[i];
+        mv<P, P>(r.G, dm, gm);
+        // G [L_s | R^{1/2}]: the left half in the order of mm<P, P, 2 P>, the right half from the record
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                double acc = r.G[i][0] * Ls[0][j];
+#pragma unroll
+                for (int k = 1; k < P; ++k) acc = fma(r.G[i][k], Ls[k][j], acc);
+                GA[i][j] = acc;
+                GA[i][P + j] = r.GR[i][j];
+            }
+        add_sqrt<P, 2 * P, P>(GA, r.JL, Ls);                     // square_root.py:217-218
+        double* mo = a.mean + ((size_t)n * a.D + blk) * P * B + b;
+        double* vo = a.var + ((size_t)n * a.D + blk) * P * P * B + b;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            ms[i] = r.mf[i] + gm[i];
+            mo[(size_t)i * B] = ms[i];
+#pragma unroll
+            for (int j = 0; j < P; ++j) vo[((size_t)i * P + j) * B] = Ls[i][j];
+        }
+        const int nn = n - RD;                                   // refill the slot (indices below 1: a harmless reload)
+        load(nn >= 1 ? nn : 1, r);
+    };
+    int n = a.N - 1;
+    while (n >= RD) {
+#pragma unroll
+        for (int s = 0; s < RD; ++s) step(n - s, q[s]);
+        n -= RD;
+    }
+#pragma unroll
+    for (int s = 0; s < RD; ++s)
+        if (s < n) step(n - s, q[s]);                            // (uniform)
+}
+
+size_t sqrt_ws_doubles(const rk_solve_cfg* c, int mode) {
+    if (mode != RK_MODE_MV || c->n_steps < 2) return 0;
+    return (size_t)c->n_steps * c->n_block * sqrt_rec_doubles(c->n_bstate) * (size_t)c->n_traj;
+}
+
 // RK_FLAG_STORE_PRED (_solve_filter's "state_pred" in square-root form): the predicted means and FACTORS are a function of the
 // filtered ones and the prior alone, pred[n + 1] = sqrt_predict(filt[n]) (square_root.py:56-57), so they are re-evaluated for
 // all time steps at once behind the forward pass -- the same arithmetic as inside it, one lane per (time, block, trajectory);
@@ -180,7 +290,7 @@ static int launch_fwd_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& 
 bool is_user_rhs(int rhs_id);
 int user_forward_sqrt(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a);
 
-int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a_, int mode) {
+int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a_, int mode, double* ws, size_t ws_bytes) {
     RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 8, RK_ERR_UNSUPPORTED, "square-root solver supports n_bstate in [2, 8], got %d",
                c->n_bstate);
     const SolveArgs& a = a_;
@@ -206,6 +316,27 @@ int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a_, int mode
     }
     if (mode == RK_MODE_FILTER) return RK_OK;
     const dim3 grid(div_up(a.B * a.D, 64)), block(64);
+    const size_t need = sqrt_ws_doubles(c, mode) * sizeof(double);
+    if (mode == RK_MODE_MV && need && ws && ws_bytes >= need) {       // (no workspace: the one-kernel form below)
+        const size_t lanes = (size_t)(a.N - 1) * a.D * (size_t)a.B;
+        RK_REQUIRE(lanes < 0x7fffffffull * 64, RK_ERR_UNSUPPORTED, "square-root solver: too many (time, block, trajectory) items for one launch");
+        const dim3 ggrid((unsigned)((lanes + 63) / 64));
+        {
+            LaunchTimer t(h, "sqrt_gain_kernel");
+#define RK_SQG(P_) case P_: hipLaunchKernelGGL((sqrt_gain_kernel<P_>), ggrid, block, 0, h->stream, a, ws); break;
+            switch (c->n_bstate) { RK_SQG(2) RK_SQG(3) RK_SQG(4) RK_SQG(5) RK_SQG(6) RK_SQG(7) RK_SQG(8) }
+#undef RK_SQG
+            t.stop();
+            RK_HIP(hipGetLastError());
+        }
+        LaunchTimer t(h, "bwd_sqrt_chain_kernel");
+#define RK_SQC(P_) case P_: hipLaunchKernelGGL((bwd_sqrt_chain_kernel<P_>), grid, block, 0, h->stream, a, ws); break;
+        switch (c->n_bstate) { RK_SQC(2) RK_SQC(3) RK_SQC(4) RK_SQC(5) RK_SQC(6) RK_SQC(7) RK_SQC(8) }
+#undef RK_SQC
+        t.stop();
+        RK_HIP(hipGetLastError());
+        return RK_OK;
+    }
     LaunchTimer t(h, mode == RK_MODE_SIM ? "bwd_sqrt_sim_kernel" : "bwd_sqrt_mv_kernel");
 #define RK_SQ(P_)                                                                                        \
     case P_:                                                                                             \
