@@ -187,10 +187,14 @@ int rk_solve_layout(const rk_solve_cfg* cfg, int32_t mode, int32_t* layout);
  * RK_LAYOUT_TILE4 likewise (20 doubles per tile + 128 per wave); always size tile buffers with this function.   */
 int rk_solve_sizes(const rk_solve_cfg* cfg, int32_t layout, size_t* mean_bytes, size_t* var_bytes);
 
-/* bytes of device scratch (rk_solve_out.workspace) the configuration needs; 0 for the small-block kernels.  Dense path
+/* bytes of device scratch (rk_solve_out.workspace) the configuration needs; 0 for the standard small-block kernels.  Dense path
  * with RK_KALMAN_SQRT and mode != RK_MODE_FILTER: per-trajectory scratch PLUS the predicted factors of every step,
  * (B, N+1, p, p) doubles (src/rodeo/kalmantv/square_root.py:170-175 solves with them in the backward pass), unless
- * RK_FLAG_STORE_PRED hands the caller's var_pred to the library for that purpose.                                     */
+ * RK_FLAG_STORE_PRED hands the caller's var_pred to the library for that purpose.
+ * Blocked tile path (n_bstate 4..8): the hand-off records of the two-kernel backward passes (solve_sim; solve_mv only with
+ * RK_TILEN_BWD=split -- the default one-kernel solve_mv needs none of it, the size is still reported for that switch).
+ * Small blocks with RK_KALMAN_SQRT, rk_solve_mv: (N, d, 3p^2 + p, B) doubles of records for the two-kernel backward pass;
+ * OPTIONAL -- with workspace = NULL (or too small) the one-kernel backward pass runs, same results, about twice the time. */
 int rk_solve_workspace_bytes(const rk_solve_cfg* cfg, int32_t mode, size_t* bytes);
 
 /* forward pass only: src/rodeo/solve.py:31-122 (_solve_filter).  out->mean_state/var_state <- filtered. */

@@ -9,6 +9,7 @@
 // same): interrogate_rodeo hands W L- W^T and interrogate_chkrebtii hands W L- (1 x p) to the update as the
 // "factor" of var_meas (src/rodeo/interrogate.py:36-42, 110-113).  One quirk is NOT kept: solve_sim's draws use
 // N(mean, L L^T) (the reference passes the factor where jax expects a covariance, solve.py:179).
+#include <cstdlib>
 #include "common.hpp"
 #include "kalman_small.hpp"
 #include "philox.hpp"
@@ -317,7 +318,8 @@ int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a_, int mode
     if (mode == RK_MODE_FILTER) return RK_OK;
     const dim3 grid(div_up(a.B * a.D, 64)), block(64);
     const size_t need = sqrt_ws_doubles(c, mode) * sizeof(double);
-    if (mode == RK_MODE_MV && need && ws && ws_bytes >= need) {       // (no workspace: the one-kernel form below)
+    const char* const bsel = getenv("RK_SQRT_BWD");                   // "single": the one-kernel form (the parity test's other leg)
+    if (mode == RK_MODE_MV && need && ws && ws_bytes >= need && !(bsel && bsel[0] == 's')) {       // (no workspace: the one-kernel form below)
         const size_t lanes = (size_t)(a.N - 1) * a.D * (size_t)a.B;
         RK_REQUIRE(lanes < 0x7fffffffull * 64, RK_ERR_UNSUPPORTED, "square-root solver: too many (time, block, trajectory) items for one launch");
         const dim3 ggrid((unsigned)((lanes + 63) / 64));

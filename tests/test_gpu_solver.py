@@ -480,6 +480,37 @@ def test_square_root_solver_parity(ra, name):
             assert np.max(np.abs(res) / scale) < 1e-9, np.max(np.abs(res) / scale)
 
 
+@pytest.mark.parametrize("p", [3, 5, 8])
+def test_square_root_backward_forms_agree(ra, p, monkeypatch):
+    """solve_mv in square-root form on small blocks: the two-kernel backward pass (carry-independent part of every step
+    time-parallel into a workspace, then the chain; rodeo_amd/csrc/solve_sqrt.hip) and the one-kernel pass that runs without a
+    workspace do the same arithmetic in the same order: the same bits.  RK_SQRT_BWD is read per call."""
+    rng = np.random.default_rng(11 + p)
+    B, N = 5, 23
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.1 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0 = init(np.array([-1., 1.]) + 0.1 * rng.standard_normal((B, 2)), 0.0, theta=theta)
+    Q, R = ra.ibm_init(1.0 / N, p, np.array([.1, .1]))
+    if p >= 7:                                           # (the IBM variance matrix is singular in fp64 there)
+        Lr = np.tril(0.1 * rng.standard_normal((2, p, p))) + np.eye(p) * 0.5
+    else:
+        Lr = np.linalg.cholesky(R)
+    res = {}
+    for form in ("two", "single"):
+        monkeypatch.setenv("RK_SQRT_BWD", form)
+        plan = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, x0, 0.0, 1.0, N, ra.interrogate.interrogate_kramer, (Q, Lr),
+                            kalman_type="square-root", theta=theta)
+        plan.dev.profile_enable(True)
+        plan.mv(None)
+        names = [k for k, _ in plan.dev.profile_last()]
+        plan.dev.profile_enable(False)
+        assert ("bwd_sqrt_chain_kernel" in names) == (form == "two"), names
+        res[form] = plan.state_host()
+    assert np.all(np.isfinite(res["two"][0])) and np.all(np.isfinite(res["two"][1]))
+    np.testing.assert_array_equal(res["two"][0], res["single"][0])
+    np.testing.assert_array_equal(res["two"][1], res["single"][1])
+
+
 def test_square_root_higher_order_example(ra):
     """The docs' square-root run (higher_order.md:109-125): n_deriv = 4 second-order ODE, vs the analytic solution."""
     W = np.array([[[0., 0., 1., 0.]]]); x0 = np.array([[-1., 0., 1., 0.]])
