@@ -263,6 +263,31 @@ def test_blocked_tiles_gain_variants_agree(ra, p, B, N, monkeypatch):
         np.testing.assert_array_equal(res["lanes"][1], res[form][1])
 
 
+@pytest.mark.parametrize("p", [5, 8])
+@pytest.mark.parametrize("mode", ["mv", "sim"])
+def test_blocked_tiles_per_trajectory_priors(ra, p, mode):
+    """Prior matrices that differ between trajectories (the pseudo-marginal sampler's sigma per draw, and here a weight matrix
+    per trajectory too): the batched-input indexing of the forward kernel, of the gain items on DPP rows and of the
+    lane-per-item gain kernel (solve_sim) against the oracle."""
+    B, N, t_max = 6, 40, 0.4
+    rng = np.random.default_rng(50 + p)
+    s = _fitz(ra, p, B=B, seed=3, N=N, t_max=t_max)
+    sig = 0.1 * np.exp(0.3 * rng.standard_normal((B, 2)))
+    Qs, Rs = zip(*[ra.ibm_init(t_max / N * (1.0 + 0.05 * b), p, sig[b]) for b in range(B)])
+    prior = (np.stack(Qs), np.stack(Rs))                                  # (B, 2, p, p) each
+    args = (s["W"], s["x0"], 0.0, t_max, N)
+    g, o = _itg(ra, "kramer")
+    if mode == "mv":
+        m, v = ra.solve_mv(None, ra.ode.fitzhugh_nagumo, *args, g, prior, theta=s["theta"])
+        mo, vo = scan.solve_mv(None, odes.fitzhugh_nagumo, *args, o, prior, theta=s["theta"])
+        _close(m, mo, v, vo, p, prior[1][0], entrywise=False)
+    else:
+        x = ra.solve_sim(4, ra.ode.fitzhugh_nagumo, *args, g, prior, theta=s["theta"])
+        xo = scan.solve_sim(4, odes.fitzhugh_nagumo, *args, o, prior, theta=s["theta"])
+        scale = np.maximum(np.max(np.abs(xo), axis=(0, 1, 2)), 1.0)
+        assert np.max(np.abs(x - xo) / scale) < (1e-6 if p == 5 else 1e-4)
+
+
 @pytest.mark.parametrize("p,rhs", [(5, "lorenz63"), (6, "lorenz63"), (6, "higher_order"), (8, "higher_order")])
 def test_blocked_tiles_other_block_counts(ra, p, rhs):
     """n_block = 3 (one trajectory per wave, three units) and n_block = 1 (four trajectories per wave)."""
