@@ -592,12 +592,10 @@ __device__ __forceinline__ void trsm16(double (&x)[LU_NB], const double* prow0, 
 // Net row permutation of one panel applied to `ncols` columns of M (row stride ld, rows relative to k0): one thread
 // per column loads the (at most 32) moved rows of its column and stores them to their new places -- no barrier, no
 // thread touches another thread's column.  Row bases are uniform (scalar), the column is the per-thread offset.
-__device__ __forceinline__ void lu_swap_cols(gd* M, int ld, int ncols, int nm) {
-    // the moved rows' destinations and sources: read once per wave (lane li holds entry li), handed out by readlane
-    const int l = threadIdx.x & 63;
-    const int my_dst = l < nm ? g_mlist[l] : 0;
-    const int my_src = l < nm ? g_cur[my_dst] : 0;
-    for (int cc = threadIdx.x; cc < ncols; cc += DT) {
+__device__ __forceinline__ void lu_swap_cols(gd* M, int ld, int ncols, int nm, int my_dst, int my_src, int t0 = threadIdx.x, int nt = DT) {
+    // my_dst / my_src: the moved rows' destinations and sources, entry li in lane li of every wave (lu_swap_lists), handed out
+    // by readlane
+    for (int cc = t0; cc < ncols; cc += nt) {
         double tmp[2 * LU_NB];
 #pragma unroll
         for (int li = 0; li < 2 * LU_NB; ++li)
@@ -607,13 +605,19 @@ __device__ __forceinline__ void lu_swap_cols(gd* M, int ld, int ncols, int nm) {
             if (li < nm) (M + __builtin_amdgcn_readlane(my_dst, li) * ld)[cc] = tmp[li];
     }
 }
+__device__ __forceinline__ void lu_swap_lists(int nm, int& my_dst, int& my_src) {
+    const int l = threadIdx.x & 63;
+    my_dst = l < nm ? g_mlist[l] : 0;
+    my_src = l < nm ? g_cur[my_dst] : 0;
+}
 
 // X = L11^{-1} M for the 16-row block M (row stride ld, `ncols` columns; unit lower triangle from the LDS panel), one
 // thread per column; results to memory and to the LDS strip at column offset `soff` (zero in the padding columns up
 // to `npad` and in rows >= nb)
-__device__ __forceinline__ void lu_trsm_lower(gd* M, int ld, int ncols, int npad, int nb, double* us, int usp, int soff, int poff = 0) {
+__device__ __forceinline__ void lu_trsm_lower(gd* M, int ld, int ncols, int npad, int nb, double* us, int usp, int soff, int poff = 0,
+                                              int t0 = threadIdx.x, int nt = DT) {
     const double* const panel = g_lds + poff;
-    for (int c = threadIdx.x; c < npad; c += DT) {
+    for (int c = t0; c < npad; c += nt) {
         asm volatile("" ::: "memory");
         const bool ok = c < ncols;
         double x[LU_NB];
@@ -678,8 +682,10 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
     // Look-ahead (when two panel buffers fit): after the swaps and the L11 solves of panel k, the rank-16 update is applied
     // FIRST to the 16 columns of the next panel by all waves; then wave 0 copies and factors panel k + 1 (wave-synchronous,
     // no workgroup barrier inside) while waves 1-7 apply the update to the other columns and to the right-hand sides.
-    const bool la = 2 * n * LU_LD + LU_NB * usp <= LDS_DOUBLES;
-    const int us_off = (la ? 2 : 1) * n * LU_LD;
+    // (two panel buffers of n + 16 rows: the 16 rows in front of a panel hold the U12 block of ITS columns while wave 0 prepares it)
+    const bool la = 2 * (n + LU_NB) * LU_LD + LU_NB * usp <= LDS_DOUBLES;
+    const int pbs = (n + LU_NB) * LU_LD;                        // doubles per panel buffer (look-ahead form)
+    const int us_off = la ? 2 * pbs : n * LU_LD;
     auto copy_panel = [&](int k0, int poff, int t0, int nt) {              // rows k0.., columns k0 .. k0 + nb - 1 -> LDS
         const int nb = min(LU_NB, n - k0), rows = n - k0;
         double* const pn = lds + poff;
@@ -690,14 +696,14 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         for (int r = t0; r < rows; r += nt) g_cur[r] = r;
         if (t0 == 0) g_mcount = 0;
     };
-    copy_panel(0, 0, tid, DT);
+    copy_panel(0, la ? LU_NB * LU_LD : 0, tid, DT);
     __syncthreads();
-    if (tid < 64) lu_panel_wave(n, min(LU_NB, n), 0);
+    if (tid < 64) lu_panel_wave(n, min(LU_NB, n), la ? LU_NB * LU_LD : 0);
     __syncthreads();
     RK_STAMP(1);
     for (int k0 = 0; k0 < n; k0 += LU_NB) {
         const int nb = min(LU_NB, n - k0), rows = n - k0, n_right = n - k0 - nb;
-        const int poff = la ? ((k0 / LU_NB) & 1) * n * LU_LD : 0;
+        const int poff = la ? ((k0 / LU_NB) & 1) * pbs + LU_NB * LU_LD : 0;
         double* const panel = lds + poff;
         // the diagonal block back to A (its upper triangle is U11, needed by the back substitution); pivots
         if (tid < nb * LU_NB) {
@@ -708,46 +714,141 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         for (int r = tid; r < rows; r += DT)                          // rows whose content changed
             if (g_cur[r] != r) g_mlist[atomicAdd(&g_mcount, 1)] = r;
         __syncthreads();
-        {
-            const int nm = g_mcount;
-            if (nm > 0) {
-                lu_swap_cols(A + (size_t)k0 * lda + k0 + nb, lda, n_right, nm);
-                lu_swap_cols(Bm + (size_t)k0 * ldb, ldb, nr, nm);
-            }
-        }
-        __syncthreads();
-        RK_STAMP(2);
+        const int nm = g_mcount;
+        int my_dst, my_src;
+        lu_swap_lists(nm, my_dst, my_src);                             // (in registers before the next panel resets g_cur)
         const int nrt = (n_right + 15) & ~15;                         // trailing columns padded to whole tiles
-        lu_trsm_lower(A + (size_t)k0 * lda + k0 + nb, lda, n_right, nrt, nb, lds + us_off, usp, 0, poff);
-        lu_trsm_lower(Bm + (size_t)k0 * ldb, ldb, nr, nbp, nb, lds + us_off, usp, nrt, poff);
-        __syncthreads();
-        RK_STAMP(3);
         const int rt = (n_right + 15) >> 4;
-        if (n_right > 0 && la) {
-            // the next panel's columns first ...
-            lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off, usp, rt, (double*)(A + (size_t)(k0 + nb) * lda + k0 + nb), lda,
-                           min(LU_NB, n_right), 1, (double*)(Bm + (size_t)(k0 + nb) * ldb), ldb, 0, 0, nrt, n_right);
-            __syncthreads();
-            // ... then wave 0 factors them while the others update the rest
-            if (tid < 64) {
-                const int k1 = k0 + nb, p1 = (((k1 / LU_NB) & 1)) * n * LU_LD;
-                copy_panel(k1, p1, tid, 64);
+        gd* const A12 = A + (size_t)k0 * lda + k0 + nb;               // rows k0 .., the columns right of the panel
+        gd* const B1 = Bm + (size_t)k0 * ldb;
+        double* const A22 = (double*)(A + (size_t)(k0 + nb) * lda + k0 + nb);
+        double* const B2 = (double*)(Bm + (size_t)(k0 + nb) * ldb);
+        if (la && n_right > 0) {
+            // Every wave owns a strip of columns and takes it through the whole step by itself -- row interchanges, L11 solve
+            // (one lane per column, its U12 entries into the LDS strip), rank-16 update of the tiles below -- with no
+            // workgroup barrier in between: wave 0 owns the next panel's 16 columns and goes straight on to copy and factor
+            // that panel (the serial chain that bounds the solve: 16 column steps of ~2.4 k cycles), waves 1-7 share the other
+            // columns and the right-hand sides.  (The first version ran interchanges, solves and the next panel's update as
+            // workgroup phases in FRONT of the panel: 735 k cycles per 160 x 160 solve with 160 right-hand sides, of which
+            // 250 k were those phases.)
+            __syncthreads();                                           // every wave has its copy of the interchange lists
+            const int wave = uni((int)(tid >> 6)), lane = tid & 63;
+#ifdef RK_DENSE_STAMPS
+            const long long tw0_ = __builtin_amdgcn_s_memtime();
+#define RK_WSTAMP(k, t_from) do { if (stamps_ && blockIdx.x == 0 && lane == 0) stamps_[-2 - (k)] += (double)(__builtin_amdgcn_s_memtime() - (t_from)); } while (0)
+#else
+#define RK_WSTAMP(k, t_from)
+#endif
+            if (wave == 0) {
+                // The next panel's block column never goes back to memory: its rows k0 .. n - 1 come into the other panel
+                // buffer WITH the interchanges applied on the way (position r <- row g_cur[r]), the L11 solve of its top
+                // 16 rows and the rank-16 update of the rows below run on LDS, and only the U12 block (back substitution) is
+                // stored.  One memory round trip on the chain per panel where interchange, solve, update, store and
+                // copy were five (42 k of the 71 k cycles per panel; a round trip to this data is ~5 k cycles).
+                const int nxt = min(LU_NB, n_right), k1 = k0 + nb;
+                double* const nb1 = lds + (((k1 / LU_NB) & 1)) * pbs;    // rows 0 .. 15: rows k0 .. of the block column; then the panel
+                {
+                    // (source rows first, then all loads of a pass, then the LDS writes: a rolled loop waited for every load in turn;
+                    //  loads are clamped, not masked -- a select behind a load makes hipcc wait for that load at once)
+                    constexpr int CH = 20;                             // 160 rows x 16 columns = 40 elements per lane: two passes (one pass of 40: slower)
+                    const int total = rows * LU_NB;
+                    for (int e0 = lane; e0 < total; e0 += 64 * CH) {
+                        int srow[CH];
+                        double val[CH];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) srow[u] = g_cur[min(e0 + 64 * u, total - 1) >> 4];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) val[u] = A12[(size_t)srow[u] * lda + min((e0 + 64 * u) & 15, nxt - 1)];
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            const int e = e0 + 64 * u;
+                            if (e < total) nb1[(e >> 4) * LU_LD + (e & 15)] = (e & 15) < nxt ? val[u] : 0.0;
+                        }
+                    }
+                }
                 wave_lds_sync();
-                lu_panel_wave(n - k1, min(LU_NB, n - k1), p1);
+                if (lane < LU_NB) {
+                    double x[LU_NB];
+#pragma unroll
+                    for (int j = 0; j < LU_NB; ++j) x[j] = j < nb ? nb1[j * LU_LD + lane] : 0.0;
+                    trsm16<true, true>(x, panel, nb, nullptr);
+#pragma unroll
+                    for (int j = 0; j < LU_NB; ++j) {
+                        if (lane < nxt && j < nb) A12[(size_t)j * lda + lane] = x[j];
+                        lds[us_off + j * usp + lane] = x[j];
+                    }
+                }
+                wave_lds_sync();
+                {
+                    const int lo = lane & 15, hi = lane >> 4;
+                    const double* const lp = lds + poff + nb * LU_LD;
+                    const double* const us = lds + us_off;
+                    double* const pn = nb1 + LU_NB * LU_LD;                // the panel proper: rows k1 ..
+                    for (int rb = 0; rb < rt; ++rb) {
+                        const int li = min(rb * 16 + lo, n_right - 1);
+                        d4 acc;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[v] = pn[(rb * 16 + 4 * v + hi) * LU_LD + lo];
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq) {
+                            const int k = 4 * kq + hi;
+                            const double a_ = k < nb ? -lp[li * LU_LD + k] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, us[k * usp + lo], acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (rb * 16 + 4 * v + hi < n_right) pn[(rb * 16 + 4 * v + hi) * LU_LD + lo] = acc[v];
+                    }
+                }
+                for (int r = lane; r < n - k1; r += 64) g_cur[r] = r;
+                if (lane == 0) g_mcount = 0;
+                wave_lds_sync();
+                RK_WSTAMP(2, tw0_);                                    // (stamps build: wave 0 up to the panel; then with the panel)
+                lu_panel_wave(n - k1, min(LU_NB, n - k1), (((k1 / LU_NB) & 1)) * pbs + LU_NB * LU_LD);
+                RK_WSTAMP(3, tw0_);
             } else {
-                // column tiles 1 .. of the trailing matrix (strip offset 16), then the right-hand sides
-                lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off + LU_NB, usp, rt,
-                               (double*)(A + (size_t)(k0 + nb) * lda + k0 + nb + LU_NB), lda, max(n_right - LU_NB, 0), (nrt >> 4) - 1,
-                               (double*)(Bm + (size_t)(k0 + nb) * ldb), ldb, nr, nbp >> 4, nrt - LU_NB, n_right, 1, NWAVE - 1);
+                // column tiles in the order: trailing tiles 1 .. ta - 1, right-hand-side tiles 0 .. tb - 1
+                const int ta = nrt >> 4, tb = nbp >> 4, T = ta - 1 + tb, per = (T + NWAVE - 2) / (NWAVE - 1);
+                const int g0 = (wave - 1) * per, g1 = min(T, g0 + per);
+                if (g0 < g1) {
+                    const int a0 = min(g0, ta - 1), a1 = min(g1, ta - 1);
+                    const int b0 = max(g0 - (ta - 1), 0), b1 = max(g1 - (ta - 1), 0);
+                    const int ca = 16 * (1 + a0), cb = 16 * b0;         // first column of the strip in A12 / in B1
+                    const int nAc = a1 > a0 ? min(n_right - ca, 16 * (a1 - a0)) : 0;
+                    const int nBc = b1 > b0 ? min(nr - cb, 16 * (b1 - b0)) : 0;
+                    if (a1 > a0) {
+                        if (nm > 0) lu_swap_cols(A12 + ca, lda, nAc, nm, my_dst, my_src, lane, 64);
+                        lu_trsm_lower(A12 + ca, lda, nAc, 16 * (a1 - a0), nb, lds + us_off, usp, ca, poff, lane, 64);
+                    }
+                    if (b1 > b0) {
+                        if (nm > 0) lu_swap_cols(B1 + cb, ldb, nBc, nm, my_dst, my_src, lane, 64);
+                        lu_trsm_lower(B1 + cb, ldb, nBc, 16 * (b1 - b0), nb, lds + us_off, usp, nrt + cb, poff, lane, 64);
+                    }
+                    wave_lds_sync();
+                    lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off + ca, usp, rt, A22 + ca, lda, nAc, a1 - a0,
+                                   B2 + cb, ldb, nBc, b1 - b0, nrt + cb - ca, n_right, wave, 1);
+                }
+                if (wave == 1) RK_WSTAMP(6, tw0_);                     // (stamps build: wave 1's whole strip)
             }
-        } else if (n_right > 0) {
-            lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off, usp, rt,
-                           (double*)(A + (size_t)(k0 + nb) * lda + k0 + nb), lda, n_right, nrt >> 4,
-                           (double*)(Bm + (size_t)(k0 + nb) * ldb), ldb, nr, nbp >> 4, nrt, n_right);
+#undef RK_WSTAMP
+        } else {
+            if (nm > 0) {
+                lu_swap_cols(A12, lda, n_right, nm, my_dst, my_src);
+                lu_swap_cols(B1, ldb, nr, nm, my_dst, my_src);
+            }
             __syncthreads();
-            copy_panel(k0 + nb, 0, tid, DT);
+            RK_STAMP(2);
+            lu_trsm_lower(A12, lda, n_right, nrt, nb, lds + us_off, usp, 0, poff);
+            lu_trsm_lower(B1, ldb, nr, nbp, nb, lds + us_off, usp, nrt, poff);
             __syncthreads();
-            if (tid < 64) lu_panel_wave(n_right, min(LU_NB, n_right), 0);
+            RK_STAMP(3);
+            if (n_right > 0) {
+                lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off, usp, rt, A22, lda, n_right, nrt >> 4, B2, ldb, nr, nbp >> 4, nrt, n_right);
+                __syncthreads();
+                copy_panel(k0 + nb, 0, tid, DT);
+                __syncthreads();
+                if (tid < 64) lu_panel_wave(n_right, min(LU_NB, n_right), 0);
+            }
         }
         __syncthreads();
         RK_STAMP(4);
