@@ -123,6 +123,9 @@ __shared__ double g_qd[BD_MAXP * BD_MAX];         // diagonal blocks of a block-
 // C (M x N, ldc) = ce * E + cab * op(A) op(B); row-major operands in global memory, the whole workgroup cooperates.
 // (A rectangle-per-wave tile ownership -- 3 A + 5 B fragments from LDS for 15 MFMAs instead of two reads per MFMA -- was built
 // and measured 10-35 % SLOWER in round 3: the tiles' per-MFMA guards cost more than the fragment reads save.)
+// (So was a software-pipelined staging -- the next chunk's operands loaded into 24 registers per thread behind the current chunk's
+// MFMAs, stored to LDS after the barrier: with 13 accumulator tiles per wave the function spills (253 scratch instructions, most
+// of them in the chunk loop) and the products ran 30-50 % slower.)
 // v_mfma_f64_16x16x4_f64 with BOTH operands staged through LDS in k-chunks of 32 (As[k][i], Bs[k][j], row stride 177
 // doubles: the fragment reads and the transposing stores are both at most 2-way on the banks), so a transposed operand
 // only changes how its chunk is staged and there is ONE copy of the inner loop: the kernels issue their products
