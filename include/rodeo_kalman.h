@@ -218,9 +218,10 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
 
 /* Fenrir's backward pass (src/rodeo/inference/fenrir.py:86-259; the forward pass is rk_solve_filter with the same
  * cfg / in, fenrir.py:304-313): log p(y_{0:M} | Z_{1:N}) per trajectory from the filter's output in `out` -- either
- * the RK_LAYOUT_TILE3 tiles (no flags; predicted moments are re-evaluated on the fly) when rk_solve_layout reports that
- * layout for RK_MODE_FILTER, or the batch-minor filtered and predicted moments of a call with
- * RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR (required when n_bobs > 1).  Observations (fenrir.py:106-122), n_bobs = 1..3
+ * the RK_LAYOUT_TILE3 tiles (no flags; predicted moments are re-evaluated on the fly; n_bobs = 1) or the RK_LAYOUT_TILE4 /
+ * RK_LAYOUT_TILEP records (no flags; n_bstate 4..8, any n_bobs) when rk_solve_layout reports that layout for
+ * RK_MODE_FILTER, or the batch-minor filtered and predicted moments of a call with
+ * RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR (n_bstate 2..6; required at n_bstate = 3 when n_bobs > 1).  Observations (fenrir.py:106-122), n_bobs = 1..3
  * per block: obs (n_obs, d, n_bobs), obs_weight (n_obs, d, n_bobs, p), obs_var (n_obs, d, n_bobs, n_bobs) row-major on
  * device, shared by all trajectories; obs_ind (n_obs) = searchsorted(sim_times, obs_times), ascending.  logdens (B) is
  * overwritten.  The log-density follows src/rodeo/utils.py:60-78 (eigendecomposition of the forecast variance;

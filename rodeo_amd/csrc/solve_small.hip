@@ -30,6 +30,20 @@ __device__ __forceinline__ void load_filt(const SolveArgs& a, int n, int blk, in
     }
 }
 
+// the same from the blocked tile path's records [Sigma row-major (p^2) | mu (p)] per (time, trajectory, block)
+// (RK_LAYOUT_TILE4 / RK_LAYOUT_TILEP, solve_tilen_kernels.hpp)
+template <int P>
+__device__ __forceinline__ void load_filt_tiles(const SolveArgs& a, const double* tiles, int n, int blk, int b, double (&mf)[P],
+                                                double (&Sf)[P][P]) {
+    const double* rec = tiles + ((size_t)n * a.B * a.D + (size_t)b * a.D + blk) * (P * P + P);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        mf[i] = rec[P * P + i];
+#pragma unroll
+        for (int j = 0; j < P; ++j) Sf[i][j] = rec[i * P + j];
+    }
+}
+
 template <int P>
 __global__ void __launch_bounds__(64) bwd_mv_kernel(SolveArgs a) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,11 +177,14 @@ __global__ void __launch_bounds__(64) gauss_logpost_kernel(int B, int n_steps, i
 // time and the Markov weights A_n are kept in `states`: per (time n, block) an item of 3 P^2 + 2 P doubles
 // [m_pred (P), S_pred (P^2), m_filt (P), S_filt (P^2), A (P^2)], batch-minor.
 // MO = n_bobs (observations per block, fenrir.py:106-122): obs (n_obs, d, MO), obs_w (n_obs, d, MO, P), obs_v (n_obs, d, MO, MO)
-template <int P, bool STORE, int MO>
+// TILES: the forward pass ran on the blocked MFMA tiles (n_bstate 4 .. 8): `tiles` holds its records and the predicted
+// moments are re-evaluated from the filtered ones (standard.py:57-59, what the forward pass computed) instead of read.
+template <int P, bool STORE, int MO, bool TILES = false>
 __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const double* __restrict__ obs,
                                                         const double* __restrict__ obs_w, const double* __restrict__ obs_v,
                                                         const int32_t* __restrict__ obs_ind, int n_obs,
-                                                        double* __restrict__ logdens, double* __restrict__ states) {
+                                                        double* __restrict__ logdens, double* __restrict__ states,
+                                                        const double* __restrict__ tiles = nullptr) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= a.B * a.D) return;
     const int blk = l / a.B, b = l - blk * a.B;
@@ -176,7 +193,8 @@ __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const doubl
     double Q[P][P], R[P][P];
     load_block_consts<P>(a, blk, b, Q, R);
     double bm[P], bS[P][P];
-    load_filt<P>(a, a.N, blk, b, bm, bS);                                   // terminal point (fenrir.py:186-188)
+    if constexpr (TILES) load_filt_tiles<P>(a, tiles, a.N, blk, b, bm, bS);
+    else load_filt<P>(a, a.N, blk, b, bm, bS);                               // terminal point (fenrir.py:186-188)
     double acc = 0.0;
     int i = n_obs - 1;
     // forecast (standard.py:333-335) + log-density + update (standard.py:93-102) with observation i
@@ -292,8 +310,12 @@ __global__ void __launch_bounds__(64) fenrir_bwd_kernel(SolveArgs a, const doubl
     if constexpr (STORE) keep(a.N, P + P * P, bm, bS);
     for (int n = a.N - 1; n >= 0; --n) {
         double mf[P], Sf[P][P], mp[P], Sp[P][P], T[P][P], G[P][P];
-        load_filt<P>(a, n, blk, b, mf, Sf);
-        {   // stored predicted moments of time n + 1 (solve.py:93-96)
+        if constexpr (TILES) {
+            load_filt_tiles<P>(a, tiles, n, blk, b, mf, Sf);
+            predict_block<P>(Q, R, mf, Sf, mp, Sp);                         // pred[n + 1] from filt[n]
+        } else {
+            load_filt<P>(a, n, blk, b, mf, Sf);
+            // stored predicted moments of time n + 1 (solve.py:93-96)
             const double* mi = a.mean_pred + ((size_t)(n + 1) * a.D + blk) * P * B + b;
             const double* vi = a.var_pred + ((size_t)(n + 1) * a.D + blk) * P * P * B + b;
 #pragma unroll
@@ -752,9 +774,29 @@ int rk_fenrir_backward(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in
         RK_HIP(hipMemsetAsync(logdens, 0, sizeof(double) * (size_t)c->n_traj, h->stream));
         return tile3_fenrir_backward(h, at, out->var_state, obs, obs_weight, obs_var, obs_ind, n_obs, logdens);
     }
+    if (!(c->flags & (RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)) && c->n_bstate >= 4 && c->n_bstate <= 8 &&
+        (tile4_supported(c, RK_MODE_FILTER) || tilen_supported(c, RK_MODE_FILTER))) {
+        // the filter ran on the blocked MFMA tiles (n_bstate 4 .. 8): out->var_state holds its records [Sigma | mu]; the
+        // backward filter runs one lane per (block, trajectory) on them and re-evaluates the predicted moments
+        RK_REQUIRE(out->var_state && n_obs >= 0, RK_ERR_INVALID, "rk_fenrir_backward: out->var_state (tiles) is null");
+        SolveArgs at;
+        int rct = make_args(c, in, out, at);
+        if (rct) return rct;
+        RK_HIP(hipSetDevice(h->device));
+        RK_HIP(hipMemsetAsync(logdens, 0, sizeof(double) * (size_t)c->n_traj, h->stream));
+        const dim3 tgrid(div_up(at.B * at.D, 64)), tblock(64);
+        LaunchTimer t(h, "fenrir_bwd_kernel<tiles>");
+#define RK_FT(P_, M_) if (c->n_bstate == P_ && n_bobs == M_) hipLaunchKernelGGL((fenrir_bwd_kernel<P_, false, M_, true>), tgrid, tblock, 0, h->stream, at, obs, obs_weight, obs_var, obs_ind, n_obs, logdens, (double*)nullptr, (const double*)out->var_state);
+        RK_FT(4, 1) RK_FT(4, 2) RK_FT(4, 3) RK_FT(5, 1) RK_FT(5, 2) RK_FT(5, 3) RK_FT(6, 1) RK_FT(6, 2) RK_FT(6, 3)
+        RK_FT(7, 1) RK_FT(7, 2) RK_FT(7, 3) RK_FT(8, 1) RK_FT(8, 2) RK_FT(8, 3)
+#undef RK_FT
+        t.stop();
+        RK_HIP(hipGetLastError());
+        return RK_OK;
+    }
     RK_REQUIRE(out->mean_state && out->var_state && out->mean_pred && out->var_pred, RK_ERR_INVALID,
                "rk_fenrir_backward needs the batch-minor filtered AND predicted moments of rk_solve_filter "
-               "(RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR), or a configuration of the tile path (n_bstate = 3) without them");
+               "(RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR), or a configuration of the tile paths (n_bstate = 3 .. 8) without them");
     RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6 && n_obs >= 0, RK_ERR_UNSUPPORTED,
                "rk_fenrir_backward: n_bstate in 2..6");
     SolveArgs a;

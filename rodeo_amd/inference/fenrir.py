@@ -70,7 +70,7 @@ def _check_obs(obs_data, obs_weight, obs_var):
 
 
 def _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, params,
-              tiles_ok=True):
+              tiles_ok=True, tiles_blocked_ok=True):
     """A (cached, solve.cached_plan) plan on the MFMA-tile forward kernels when the configuration has them (n_bstate = 3:
     the backward pass then re-evaluates the predicted moments from the filtered tiles), else on the lane-per-trajectory
     kernels with stored predictions."""
@@ -78,7 +78,11 @@ def _plan_for(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate,
     plan = cached_plan(*args, **params)
     lay = C.c_int32(0)
     _lib.check(plan.dev.lib.rk_solve_layout(C.byref(plan.cfg), _lib.MODE_FILTER, C.byref(lay)))
-    if lay.value != _lib.LAYOUT_TILE3 or not tiles_ok:
+    # n_bstate = 3: the tile kernels (one observation per block); n_bstate = 4 .. 8: the blocked tile forward pass and a
+    # lane-per-block backward filter on its records (any n_bobs); else the lane kernels with stored predictions
+    on_tiles = (lay.value == _lib.LAYOUT_TILE3 and tiles_ok) or \
+               (lay.value in (_lib.LAYOUT_TILE4, _lib.LAYOUT_TILEP) and kalman_type == "standard" and tiles_blocked_ok)
+    if not on_tiles:
         plan = cached_plan(*args, store_pred=True, batch_minor=True, **params)
     return plan
 

@@ -30,7 +30,8 @@ SCRATCH_ALLOW = {"kalman_op_kernel": 32768,        # kalman_batched.hip: runtime
                  "15fwd_sqrt_kernel": 6144,       # solve_sqrt.hip, lane-per-trajectory square-root filter: the stacked (2p x p)
                  "15bwd_sqrt_kernel": 6144,
                  "21bwd_sqrt_chain_kernel": 4096,  # the two-kernel form's chain: three p x p record matrices + the 3p x p stack at n_bstate = 8
-                 "16sqrt_gain_kernel": 6144}       # Householder inputs of every block spill from n_bstate = 7 on (functional path)
+                 "16sqrt_gain_kernel": 6144,
+                 "17fenrir_bwd_kernel": 4096}       # lane per (block, trajectory) on the blocked tile records at n_bstate = 8       # Householder inputs of every block spill from n_bstate = 7 on (functional path)
 LDS_LIMIT = 160 * 1024
 FIELDS = ("agpr_count", "group_segment_fixed_size", "max_flat_workgroup_size", "private_segment_fixed_size",
           "sgpr_spill_count", "uses_dynamic_stack", "vgpr_count", "vgpr_spill_count")

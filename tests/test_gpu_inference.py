@@ -253,11 +253,11 @@ def test_config4_full_size_per_gpu(ra):
         np.testing.assert_array_equal(p1.x_host()[0], x[b])
 
 
-@pytest.mark.parametrize("p", [3, 4, 5, 6])
+@pytest.mark.parametrize("p", [3, 4, 5, 6, 7])        # (n_bstate = 8 on this grid: the fp64 ORACLE overflows)
 def test_fenrir_long_horizon_sparse_observations(ra, p):
     """Fenrir with few observations on a long grid: at n_bstate = 3 the MFMA-tile kernels (forward tiles, backward filter
-    with whole 16-step chunks between observations); at n_bstate = 4 the lane-per-trajectory kernels with stored
-    predictions.  Batch of 5 against the oracle."""
+    with whole 16-step chunks between observations); at n_bstate = 4 .. 8 the blocked-tile forward pass and the
+    lane-per-block backward filter on its records (predictions re-evaluated).  Batch of 5 against the oracle."""
     from oracle import fenrir as ofen
     N, t_max, n_obs, B = 200, 10.0, 4, 5
     rng = np.random.default_rng(7)
@@ -274,7 +274,17 @@ def test_fenrir_long_horizon_sparse_observations(ra, p):
                               Dw, Om, theta=theta)
     ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, oi.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
     assert val.shape == (B,)
-    np.testing.assert_allclose(val, ref, rtol=1e-7 if p <= 4 else 1e-5, atol=1e-7 if p <= 4 else 1e-5)   # (conditioning, test_gpu_tilen.py)
+    tol = {3: 1e-7, 4: 1e-7, 5: 1e-5, 6: 1e-5, 7: 1e-4}[p]                                   # (conditioning, test_gpu_tilen.py)
+    np.testing.assert_allclose(val, ref, rtol=tol, atol=tol)
+    # which kernels ran: the forward pass on tiles at every n_bstate here, no lane-per-trajectory filter
+    from rodeo_amd.solve import cached_plan
+    plan = cached_plan(ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, prior, "standard", theta=theta)
+    plan.dev.profile_enable(True)
+    ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, ra.interrogate.interrogate_kramer, prior, y, obs_times, Dw, Om, theta=theta)
+    names = [k for k, _ in plan.dev.profile_last()]
+    plan.dev.profile_enable(False)
+    assert any(k.startswith("fwd_tile") for k in names), names
+    assert any("fenrir" in k and ("tile" in k) for k in names), names
 
 
 @pytest.mark.parametrize("N", [1, 2, 16, 17, 18, 33])
