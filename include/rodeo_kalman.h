@@ -193,7 +193,7 @@ int rk_solve_sizes(const rk_solve_cfg* cfg, int32_t layout, size_t* mean_bytes, 
  * RK_FLAG_STORE_PRED hands the caller's var_pred to the library for that purpose.
  * Blocked tile path (n_bstate 4..8): the hand-off records of the two-kernel backward passes (solve_sim; solve_mv only with
  * RK_TILEN_BWD=split -- the default one-kernel solve_mv needs none of it, the size is still reported for that switch).
- * Small blocks with RK_KALMAN_SQRT, rk_solve_mv: (N, d, 3p^2 + p, B) doubles of records for the two-kernel backward pass;
+ * Small blocks with RK_KALMAN_SQRT, rk_solve_mv / rk_solve_sim: (N, d, 3p^2 + p | p^2 + 2p, B) doubles of records for the two-kernel backward pass;
  * OPTIONAL -- with workspace = NULL (or too small) the one-kernel backward pass runs, same results, about twice the time. */
 int rk_solve_workspace_bytes(const rk_solve_cfg* cfg, int32_t mode, size_t* bytes);
 

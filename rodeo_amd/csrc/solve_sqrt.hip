@@ -216,9 +216,114 @@ __global__ void __launch_bounds__(64) bwd_sqrt_chain_kernel(SolveArgs a, const d
         if (s < n) step(n - s, q[s]);                            // (uniform)
 }
 
+// ---- solve_sim the same way: of a sampling step (square_root.py:252-261, solve.py:179) only G (x_{n+1} - mu-) depends on the
+// carry; the gain, the conditional factor L_sim = add_sqrt(G R^{1/2}, J L_f) and the draw's own part mu_f + L_sim z are
+// evaluated for all steps at once into a record [G | mu- | mu_f + L_sim z] of p^2 + 2 p doubles, and the chain is one
+// matrix-vector product per step.  Same arithmetic and the same normals as bwd_sqrt_kernel<P, true>.
+__host__ __device__ inline size_t sqrt_sim_rec_doubles(int p) { return (size_t)p * p + 2 * p; }
+
+template <int P>
+__global__ void __launch_bounds__(64) sqrt_sim_gain_kernel(SolveArgs a, double* __restrict__ ws) {
+    const size_t B = (size_t)a.B, per_step = (size_t)a.D * B;
+    const size_t l = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= (size_t)(a.N - 1) * per_step) return;
+    const int n = 1 + (int)(l / per_step), blk = (int)((l % per_step) / B), b = (int)(l % B);
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+    double Q[P][P], LR[P][P], mf[P], Lf[P][P], mp[P], Lp[P][P], G[P][P], JL[P][P], GR[P][P], Lsim[P][P], z[P];
+    load_block_consts<P>(a, blk, b, Q, LR);
+    load_state<P>(a, n, blk, b, mf, Lf);
+    sqrt_predict<P>(Q, LR, mf, Lf, mp, Lp);
+    sqrt_gain<P>(Q, Lf, Lp, G, JL);
+    mm<P, P, P>(G, LR, GR);
+    add_sqrt<P, P, P>(GR, JL, Lsim);                             // square_root.py:259-260
+    normals<P>(a.seed, traj, (uint32_t)n, (uint32_t)blk, PURPOSE_SMOOTH, z);
+#pragma unroll
+    for (int j = 0; j < P; ++j) z[j] = Lsim[j][j] < 0.0 ? -z[j] : z[j];
+    double* rec = ws + ((size_t)n * a.D + blk) * sqrt_sim_rec_doubles(P) * B + b;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        double w = 0.0;                                          // (the order of bwd_sqrt_kernel: (mu_f + G dx) + L z, L z summed first)
+#pragma unroll
+        for (int k = 0; k < P; ++k) w = fma(Lsim[i][k], z[k], w);
+        rec[(size_t)(P * P + i) * B] = mp[i];
+        rec[(size_t)(P * P + P + i) * B] = w;
+#pragma unroll
+        for (int j = 0; j < P; ++j) rec[(size_t)(i * P + j) * B] = G[i][j];
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(64) bwd_sqrt_sim_chain_kernel(SolveArgs a, const double* __restrict__ ws) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= a.B * a.D) return;
+    const int blk = l / a.B, b = l - blk * a.B;
+    const size_t B = (size_t)a.B;
+    const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+    double xn[P];
+    {
+        double ms[P], Ls[P][P], z[P];
+        load_state<P>(a, a.N, blk, b, ms, Ls);                   // x_N ~ N(filt[N])
+        normals<P>(a.seed, traj, (uint32_t)a.N, (uint32_t)blk, PURPOSE_SMOOTH, z);
+#pragma unroll
+        for (int j = 0; j < P; ++j) z[j] = Ls[j][j] < 0.0 ? -z[j] : z[j];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            double sacc = ms[i];
+#pragma unroll
+            for (int k = 0; k < P; ++k) sacc = fma(Ls[i][k], z[k], sacc);
+            xn[i] = sacc;
+            a.x[(((size_t)a.N * a.D + blk) * P + i) * B + b] = sacc;
+        }
+    }
+    struct Rec { double G[P][P], mp[P], w[P], mf[P]; };
+    auto load = [&](int n, Rec& q) {
+        const double* rec = ws + ((size_t)n * a.D + blk) * sqrt_sim_rec_doubles(P) * B + b;
+        const double* mi = a.mean + ((size_t)n * a.D + blk) * P * B + b;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            q.mp[i] = rec[(size_t)(P * P + i) * B];
+            q.w[i] = rec[(size_t)(P * P + P + i) * B];
+            q.mf[i] = mi[(size_t)i * B];
+#pragma unroll
+            for (int j = 0; j < P; ++j) q.G[i][j] = rec[(size_t)(i * P + j) * B];
+        }
+    };
+    constexpr int RD = P <= 4 ? 4 : 2;
+    Rec q[RD];
+#pragma unroll
+    for (int s = 0; s < RD; ++s) load(a.N - 1 - s >= 1 ? a.N - 1 - s : 1, q[s]);
+    auto step = [&](int n, Rec& r) {
+        double dm[P], gm[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) dm[i] = xn[i] - r.mp[i];
+        mv<P, P>(r.G, dm, gm);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            // bwd_sqrt_kernel: s = mu_f + gm, then fma over L z term by term; here L z arrives summed: rounding-level difference
+            xn[i] = (r.mf[i] + gm[i]) + r.w[i];
+            a.x[(((size_t)n * a.D + blk) * P + i) * B + b] = xn[i];
+        }
+        const int nn = n - RD;
+        load(nn >= 1 ? nn : 1, r);
+    };
+    int n = a.N - 1;
+    while (n >= RD) {
+#pragma unroll
+        for (int s = 0; s < RD; ++s) step(n - s, q[s]);
+        n -= RD;
+    }
+#pragma unroll
+    for (int s = 0; s < RD; ++s)
+        if (s < n) step(n - s, q[s]);
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        a.x[((size_t)blk * P + i) * B + b] = a.mean[((size_t)blk * P + i) * B + b];   // x[0] = ode_init
+}
+
 size_t sqrt_ws_doubles(const rk_solve_cfg* c, int mode) {
-    if (mode != RK_MODE_MV || c->n_steps < 2) return 0;
-    return (size_t)c->n_steps * c->n_block * sqrt_rec_doubles(c->n_bstate) * (size_t)c->n_traj;
+    if (mode == RK_MODE_FILTER || c->n_steps < 2) return 0;
+    const size_t rec = mode == RK_MODE_MV ? sqrt_rec_doubles(c->n_bstate) : sqrt_sim_rec_doubles(c->n_bstate);
+    return (size_t)c->n_steps * c->n_block * rec * (size_t)c->n_traj;
 }
 
 // RK_FLAG_STORE_PRED (_solve_filter's "state_pred" in square-root form): the predicted means and FACTORS are a function of the
@@ -333,6 +438,26 @@ int sqrt_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a_, int mode
         }
         LaunchTimer t(h, "bwd_sqrt_chain_kernel");
 #define RK_SQC(P_) case P_: hipLaunchKernelGGL((bwd_sqrt_chain_kernel<P_>), grid, block, 0, h->stream, a, ws); break;
+        switch (c->n_bstate) { RK_SQC(2) RK_SQC(3) RK_SQC(4) RK_SQC(5) RK_SQC(6) RK_SQC(7) RK_SQC(8) }
+#undef RK_SQC
+        t.stop();
+        RK_HIP(hipGetLastError());
+        return RK_OK;
+    }
+    if (mode == RK_MODE_SIM && need && ws && ws_bytes >= need && !(bsel && bsel[0] == 's')) {
+        const size_t lanes = (size_t)(a.N - 1) * a.D * (size_t)a.B;
+        RK_REQUIRE(lanes < 0x7fffffffull * 64, RK_ERR_UNSUPPORTED, "square-root solver: too many (time, block, trajectory) items for one launch");
+        const dim3 ggrid((unsigned)((lanes + 63) / 64));
+        {
+            LaunchTimer t(h, "sqrt_sim_gain_kernel");
+#define RK_SQG(P_) case P_: hipLaunchKernelGGL((sqrt_sim_gain_kernel<P_>), ggrid, block, 0, h->stream, a, ws); break;
+            switch (c->n_bstate) { RK_SQG(2) RK_SQG(3) RK_SQG(4) RK_SQG(5) RK_SQG(6) RK_SQG(7) RK_SQG(8) }
+#undef RK_SQG
+            t.stop();
+            RK_HIP(hipGetLastError());
+        }
+        LaunchTimer t(h, "bwd_sqrt_sim_chain_kernel");
+#define RK_SQC(P_) case P_: hipLaunchKernelGGL((bwd_sqrt_sim_chain_kernel<P_>), grid, block, 0, h->stream, a, ws); break;
         switch (c->n_bstate) { RK_SQC(2) RK_SQC(3) RK_SQC(4) RK_SQC(5) RK_SQC(6) RK_SQC(7) RK_SQC(8) }
 #undef RK_SQC
         t.stop();

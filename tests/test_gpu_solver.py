@@ -506,9 +506,18 @@ def test_square_root_backward_forms_agree(ra, p, monkeypatch):
         plan.dev.profile_enable(False)
         assert ("bwd_sqrt_chain_kernel" in names) == (form == "two"), names
         res[form] = plan.state_host()
+        plan.dev.profile_enable(True)
+        plan.sim(77)
+        names = [k for k, _ in plan.dev.profile_last()]
+        plan.dev.profile_enable(False)
+        assert ("bwd_sqrt_sim_chain_kernel" in names) == (form == "two"), names
+        res[form + "_x"] = plan.x_host()
     assert np.all(np.isfinite(res["two"][0])) and np.all(np.isfinite(res["two"][1]))
     np.testing.assert_array_equal(res["two"][0], res["single"][0])
     np.testing.assert_array_equal(res["two"][1], res["single"][1])
+    # solve_sim: same normals, same factors; the draw's L z arrives summed in the two-kernel form (rounding-level difference)
+    assert np.all(np.isfinite(res["two_x"]))
+    np.testing.assert_allclose(res["two_x"], res["single_x"], rtol=1e-9, atol=1e-11)
 
 
 def test_square_root_higher_order_example(ra):
