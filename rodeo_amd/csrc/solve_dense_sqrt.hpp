@@ -212,7 +212,7 @@ __device__ __noinline__ void qr_panel30(double* P, const double* Pt, int ld, int
 // T (16 x 16 upper triangular, g_lds[t_off + i * 16 + j]) of the compact WY form from the LDS panel V and tau:
 // T_jj = tau_j, T(0:j, j) = -tau_j T(0:j, 0:j) (V^T V)(0:j, j)   (LAPACK dlarft, forward / columnwise).
 // Ends WITHOUT a barrier: T is complete after the caller's next barrier.
-__device__ __noinline__ void qr_build_T(int Mk_, int gp_off_, int t_off_, int tau_off_) {
+__device__ __forceinline__ void qr_build_T(int Mk_, int gp_off_, int t_off_, int tau_off_) {
     const int Mk = uni(Mk_), gp_off = uni(gp_off_), t_off = uni(t_off_), tau_off = uni(tau_off_);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni((int)(tid >> 6)), lo = lane & 15, hi = lane >> 4;
     const double* const panel = g_lds;
@@ -257,7 +257,10 @@ __device__ __noinline__ void qr_build_T(int Mk_, int gp_off_, int t_off_, int ta
 // tile -= V_rows W' onto the registers it still holds and stores them: every element of A2 is read once and written once.
 constexpr int QF_T = 16;                                // row tiles per unit: panels of up to 512 rows
 // A2t: A2's rows from the 17th on (A2 + 16 lda, or the other block of a stack with its triangular block on top).
-__device__ __noinline__ void qr_fused_update(double* A2_, double* A2t_, int lda_, int Mk_, int n2_, int t_off_, int px_off_) {
+// (inlined into wg_qr_r, its only caller -- like the panel and T builders: as a real function it saved and restored 96 callee-saved
+// VGPRs through scratch on every call, 27 calls per QR: 49 KB per wave and call, about HALF of the forward kernel's 14.5 MB of
+// memory traffic per trajectory-step; profiles/r03_c5_pmc_traffic_dense.json)
+__device__ __forceinline__ void qr_fused_update(double* A2_, double* A2t_, int lda_, int Mk_, int n2_, int t_off_, int px_off_) {
     auto* const A2 = uni_g(A2_);
     auto* const A2t = uni_g(A2t_);
     const int lda = uni(lda_), Mk = uni(Mk_), n2 = uni(n2_), t_off = uni(t_off_), px_off = uni(px_off_);
