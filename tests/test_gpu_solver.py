@@ -520,6 +520,36 @@ def test_square_root_backward_forms_agree(ra, p, monkeypatch):
     np.testing.assert_allclose(res["two_x"], res["single_x"], rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("name", ["kramer", "chkrebtii", "rodeo"])
+def test_square_root_three_blocks_ragged_waves(ra, name):
+    """Square-root filter with THREE blocks per trajectory (Lorenz63): the forward kernel puts 64 // 3 = 21 trajectories into a
+    wave (one lane idle) and exchanges the blocks' interrogation points between neighbouring lanes; 25 trajectories = one
+    full wave and a ragged one.  solve_mv and solve_sim against the oracle."""
+    B, N, t_max, p = 25, 40, 0.4, 3
+    rng = np.random.default_rng(31)
+    theta = np.array([28., 10., 8. / 3.]) * np.exp(0.02 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, p)
+    x0 = init(np.array([-12., -5., 38.]) + 0.1 * rng.standard_normal((B, 3)), 0.0, theta=theta)
+    Q, R = ra.ibm_init(t_max / N, p, np.array([10.0] * 3))
+    pr = (Q, np.linalg.cholesky(R))
+    if name == "chkrebtii":
+        g = functools.partial(ra.interrogate.interrogate_chkrebtii, kalman_type="square-root")
+        o = functools.partial(oi.interrogate_chkrebtii, kalman_type="square-root")
+    else:
+        g, o = _itg(ra, name)
+    args = (W, x0, 0.0, t_max, N)
+    m, L = ra.solve_mv(3, ra.ode.lorenz63, *args, g, pr, kalman_type="square-root", theta=theta)
+    mo, Lo = scan.solve_mv(3, odes.lorenz63, *args, o, pr, kalman_type="square-root", theta=theta)
+    assert m.shape == (B, N + 1, 3, p) and np.all(np.isfinite(L))
+    scale = np.maximum(np.max(np.abs(mo), axis=(0, 1)), 1.0)
+    assert np.max(np.abs(m - mo) / scale) < 1e-8
+    _vclose(_sq(L), _sq(Lo), 1e-7)
+    if name != "kramer":                                 # (exact measurement: no unique sample path, test_square_root_solver_parity)
+        x = ra.solve_sim(3, ra.ode.lorenz63, *args, g, pr, kalman_type="square-root", theta=theta)
+        xo = scan.solve_sim(3, odes.lorenz63, *args, o, pr, kalman_type="square-root", theta=theta)
+        assert np.max(np.abs(x - xo) / scale) < 1e-6
+
+
 def test_square_root_higher_order_example(ra):
     """The docs' square-root run (higher_order.md:109-125): n_deriv = 4 second-order ODE, vs the analytic solution."""
     W = np.array([[[0., 0., 1., 0.]]]); x0 = np.array([[-1., 0., 1., 0.]])
