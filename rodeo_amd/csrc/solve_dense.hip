@@ -126,6 +126,8 @@ __shared__ double g_qd[BD_MAXP * BD_MAX];         // diagonal blocks of a block-
 // (So was a software-pipelined staging -- the next chunk's operands loaded into 24 registers per thread behind the current chunk's
 // MFMAs, stored to LDS after the barrier: with 13 accumulator tiles per wave the function spills (253 scratch instructions, most
 // of them in the chunk loop) and the products ran 30-50 % slower.)
+// (And the same staging restricted to the skinny m x p / p x m products of the update -- 3 accumulator tiles, no spills -- also
+// measured slower: 89 -> 115 k, 37 -> 53 k, 59 -> 69 k cycles.  The staging round trips are not what these products wait for.)
 // v_mfma_f64_16x16x4_f64 with BOTH operands staged through LDS in k-chunks of 32 (As[k][i], Bs[k][j], row stride 177
 // doubles: the fragment reads and the transposing stores are both at most 2-way on the banks), so a transposed operand
 // only changes how its chunk is staged and there is ONE copy of the inner loop: the kernels issue their products
