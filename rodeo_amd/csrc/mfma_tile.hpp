@@ -146,5 +146,10 @@ __device__ __forceinline__ void lds_dma_wait_all() {
     asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Workgroup barrier for producer / consumer kernels whose waves exchange data through LDS only: waits for this wave's LDS
+// accesses, not for its global stores and LDS-DMA loads (__syncthreads() waits vmcnt(0) too: the chain wave then stands at every
+// tick until its own stores of the tick have been written, and a producer until the prefetch it issued for three ticks later
+// has landed).  Nobody in such a kernel reads what another wave stored to global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 }  // namespace rk

@@ -151,7 +151,7 @@ __device__ __forceinline__ void tile3_gain_producers(const SolveArgs& a, const d
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();   
     }
 }
 
@@ -175,9 +175,13 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
     char* const lds_raw = lds_all;
     // this tile-wave's 64-double slice of the scratch tail (row 3 of its tiles: e_3)
     double* const dump = tiles + (size_t)(a.N + 1) * tstride + (size_t)tw * 64;
+    // (Tried: the chain wave elected by HW_ID -- the one on SIMD 0, so that the two chain waves of a CU's two workgroups share a
+    // SIMD with each other and with no producer: 0.281 against 0.264 ms; two MFMA chains on one SIMD cost more than a chain and
+    // a producer.)
+    const int role = wave;
 
-    if (wave >= 1) {
-        tile3_gain_producers(a, tiles, D, tw, wave, lane, n_tiles, tstride, n_chunks, lds_raw, zones);
+    if (role >= 1) {
+        tile3_gain_producers(a, tiles, D, tw, role, lane, n_tiles, tstride, n_chunks, lds_raw, zones);
     } else {
         // ---------------- consumer: the carry recursion on MFMA tiles ----------------
         const TileCoord tc = tile_coord<1>(tw, lane, n_tiles);              // (b, blk) not needed here
@@ -198,9 +202,9 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
         const unsigned bvoff = st ? (unsigned)((g * TILE_DOUBLES + idx) * sizeof(double)) : 0x80000000u;   // or: out of range
         const bool buffer_ok = (CHUNK - 1) * row_bytes + 384 < 0x7fffffffull;      // one chunk's rows within a 2 GiB buffer window
         const int chunk_span = (int)((CHUNK - 1) * row_bytes + 384);
-        __syncthreads();                                            // tick -3
-        __syncthreads();                                            // tick -2
-        __syncthreads();                                            // tick -1: chunk 0 is in LDS
+        lds_barrier();                                               // tick -3
+        lds_barrier();                                               // tick -2
+        lds_barrier();                                               // tick -1: chunk 0 is in LDS
         for (int t = 0; t < n_chunks; ++t) {
             const char* in = lds_raw + (t & 1) * BUF_BYTES;
             const int n_hi = a.N - 1 - t * CHUNK;
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(256) bwd_mv_tile3_kernel(SolveArgs a, double* 
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();   
         }
     }
 }

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
 #pragma unroll
                 for (int j = 0; j < P; ++j) { qr[g * QR_STRIDE + i * P + j] = Q0[i][j]; qr[g * QR_STRIDE + P * P + i * P + j] = R0[i][j]; }
         }
-        __syncthreads();                                           // (the consumer's matching barrier is its first one)
+        lds_barrier();                                              // (the consumer's matching barrier is its first one)
         int woff[16], voff[4], voff1[4];
 #pragma unroll
         for (int i = 0; i < 16; ++i) woff[i] = lds4_tile<TPW>(s, g, 0, i);
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
             const long long tC = T4_NOW();
             acc[stg] += tB - tA; acc[3] += tC - tB;
 #else
-            __syncthreads();
+            lds_barrier();   
 #endif
         }
 #if RK_T4_STAMPS >= 2
@@ -248,10 +248,10 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
             rvec[k] = lds4_vec<TPW>(k, gl, 0, r) - k * TPW * ITEM4;
             rvec1[k] = lds4_vec<TPW>(k, gl, 1, r) - k * TPW * ITEM4;
         }
-        __syncthreads();                                            // Q | R of the blocks are in LDS
-        __syncthreads();                                            // tick -3
-        __syncthreads();                                            // tick -2
-        __syncthreads();                                            // tick -1: chunk 0 is in LDS
+        lds_barrier();                                               // Q | R of the blocks are in LDS
+        lds_barrier();                                               // tick -3
+        lds_barrier();                                               // tick -2
+        lds_barrier();                                               // tick -1: chunk 0 is in LDS
 #ifdef RK_T4_STAMPS
         long long cacc[2] = {0, 0};
         const long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
             if (blockIdx.x < 8 && t < 2048 && lane == 0) dbg[(size_t)gridDim.x * 20 + (size_t)blockIdx.x * 2048 + t] = tB - tA;
 #endif
 #else
-            __syncthreads();
+            lds_barrier();   
 #endif
         }
 #ifdef RK_T4_STAMPS
