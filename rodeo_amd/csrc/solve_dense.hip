@@ -58,6 +58,7 @@ struct DenseArgs {
     double* x;                                 // solve_sim: draws, batch-minor like the lane kernels: x[(n p + i) B + b]
     double *mean_pred, *var_pred;              // RK_FLAG_STORE_PRED (_solve_filter): (B, N+1, p), (B, N+1, p, p), or null
     double* fac_pred;                          // square-root form: the predicted factors L^-_n (B, N+1, p, p) for the backward pass, or null
+    int lu_regs;                               // wg_lu_solve: 1 = register-resident forward elimination (default), 0 = panel loop over memory
 };
 
 constexpr int DT = 512, NWAVE = DT / 64;
@@ -68,7 +69,7 @@ constexpr int DT = 512, NWAVE = DT / 64;
 #define RK_STAMP_DECL(ws_end) double* const stamps_ = (double*)(ws_end); long long stamp_t_ = __builtin_amdgcn_s_memtime()
 #define RK_STAMP(k) do { __syncthreads(); if (stamps_ && blockIdx.x == 0 && threadIdx.x == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); stamps_[-2 - (k)] += (double)(t_ - stamp_t_); stamp_t_ = t_; } } while (0)
 #define RK_STAMP_RESET() stamp_t_ = __builtin_amdgcn_s_memtime()
-#define RK_STAMP_ZERO() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 12; ++k_) stamps_[-2 - k_] = 0.0; __syncthreads(); } while (0)
+#define RK_STAMP_ZERO() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 14; ++k_) stamps_[-2 - k_] = 0.0; __syncthreads(); } while (0)
 #define RK_STAMP_ZERO_N(n_) do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < (n_); ++k_) stamps_[-2 - k_] = 0.0; __syncthreads(); } while (0)
 #else
 #define RK_STAMP_ZERO_N(n_)
@@ -109,7 +110,7 @@ __device__ __forceinline__ gd* uni_g(double* ptr) { return (gd*)uni_bits(ptr); }
 __device__ __forceinline__ cgd* uni_g(const double* ptr) { return (cgd*)uni_bits(ptr); }
 __device__ __forceinline__ gi* uni_g(int* ptr) { return (gi*)uni_bits(ptr); }
 
-constexpr int LDS_DOUBLES = 16384;               // 128 KiB: GEMM staging / LU panel + U strip (one workgroup per CU)
+constexpr int LDS_DOUBLES = 17488;               // 136.6 KiB: GEMM staging / LU panel + U strip / register-resident LU (one workgroup per CU)
 // The workgroup's LDS, at file scope so that the real (non-inlined) device functions below address it as LDS: through
 // a pointer argument they would see a generic pointer and emit flat loads.
 __shared__ __attribute__((aligned(16))) double g_lds[LDS_DOUBLES];
@@ -182,7 +183,7 @@ __device__ __forceinline__ void stage_cols(double* dst, cgd* src, int ld, int kn
     }
 }
 
-__device__ __noinline__ void wg_gemm(const GemmOp& g_) {
+__device__ __noinline__ void wg_gemm_staged(const GemmOp& g_) {
     double* const lds = g_lds;
     const GemmOp& gr = *uni(&g_);
     struct { gd* C; cgd *A, *B, *E; int ldc, lda, ldb, lde, M, N, K; double ce, cab; bool ta, tb; } g;
@@ -243,6 +244,140 @@ __device__ __noinline__ void wg_gemm(const GemmOp& g_) {
             }
         }
     __syncthreads();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the same product with the operands brought into LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no
+// ds_write pass) into TWO buffers per operand, k-chunks of 16: the loads of chunk c + 1 are in flight while the MFMAs of
+// chunk c run, one barrier per chunk.  The staged version above did load -> LDS write -> barrier -> MFMA one after the
+// other and spent as long waiting for its 80 KB per chunk as multiplying (stamps of round 4: 157 k / 189 k cycles per
+// 160^3 product against 66 k of MFMA issue).  An LDS-DMA writes 64 x 16 bytes CONTIGUOUSLY (lane-linear), the source
+// address is per lane: so the LDS images are plain linear arrays and the padding that keeps the fragment reads off each
+// other's banks is filled from clamped source addresses --
+//   * an operand whose memory rows run along k ("k-major": A given transposed, B given as is): image X[k][c], row stride
+//     176 doubles (16 mod 32: the four k rows of a fragment read lie on disjoint banks), 22 DMA instructions per chunk;
+//   * an operand whose memory rows run along i / j ("row-major": A as is, B given transposed): image Y[r][k], row stride 18
+//     doubles (9 granules of 16 bytes: 8 of data, one of padding; 36 r + 2 k dwords: conflict-free), 23 instructions.
+// Same MFMAs in the same k order as the staged version: the same bits.  Needs K a multiple of 16, even leading dimensions
+// and 16-byte aligned operands (the DMA moves 16-byte granules); anything else takes the staged version.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GD_KC = 16, GD_SK = 176, GD_SR = 18, GD_BUF = 2944;         // 23 x 128 doubles >= 16 x 176, 160 x 18
+static_assert(4 * GD_BUF <= LDS_DOUBLES, "DMA GEMM buffers exceed the LDS buffer");
+
+// one chunk of one operand: KM: rows k0 .. k0 + 15 of src (row stride ld), columns c0 .. (image X[k][c]);
+// else rows r0 .. r0 + nr - 1, columns k0 .. k0 + 15 (image Y[r][k])
+template <bool KM>
+__device__ __forceinline__ void gd_issue(double* dst, cgd* src, int ld, int k0, int c0, int nvalid, int wave, int lane) {
+    constexpr int NI = KM ? 22 : 23;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int q = wave + NWAVE * r;                             // DMA instruction: granules 64 q .. 64 q + 63 of the image
+        if (q < NI) {
+            const int gidx = q * 64 + lane;
+            size_t off;
+            if (KM) {
+                const int k = gidx / 88, c2 = gidx - k * 88;
+                const int col = min(2 * c2, max(ld - c0 - 2, 0));       // (padding columns: any readable pair of this row)
+                off = (size_t)(k0 + k) * ld + c0 + col;
+            } else {
+                const int rr = gidx / 9, part = gidx - rr * 9;
+                off = (size_t)(c0 + min(rr, nvalid - 1)) * ld + k0 + 2 * min(part, 7);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                             (__attribute__((address_space(3))) void*)(dst + q * 128), 16, 0, 0);
+        }
+    }
+}
+
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void wg_gemm_dma_body(gd* C, int ldc, cgd* A, int lda, cgd* B, int ldb, int M, int N, int K,
+                                                 cgd* E, int lde, double ce, double cab) {
+    double* const lds = g_lds;
+    const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+    const int wave = uni((int)(threadIdx.x >> 6));
+    const int fragA = AKM ? hi * GD_SK + lo : lo * GD_SR + hi;
+    const int fragB = BKM ? hi * GD_SK + lo : lo * GD_SR + hi;
+    constexpr int stepA = AKM ? 4 * GD_SK : 4, stepB = BKM ? 4 * GD_SK : 4;      // per kq
+    constexpr int tileA = AKM ? 16 : 16 * GD_SR, tileB = BKM ? 16 : 16 * GD_SR;  // per tile index
+    for (int i0 = 0; i0 < M; i0 += G_MB)
+        for (int j0 = 0; j0 < N; j0 += G_MB) {
+            const int mb = min(G_MB, M - i0), nbk = min(G_MB, N - j0);
+            const int nt = (nbk + 15) >> 4, T = ((mb + 15) >> 4) * nt;
+            d4 acc[G_TPW];
+#pragma unroll
+            for (int q = 0; q < G_TPW; ++q) acc[q] = d4{0, 0, 0, 0};
+            auto issue = [&](int k0, int buf) {
+                gd_issue<AKM>(lds + buf * GD_BUF, A, lda, k0, i0, mb, wave, lane);
+                gd_issue<BKM>(lds + (2 + buf) * GD_BUF, B, ldb, k0, j0, nbk, wave, lane);
+            };
+            __syncthreads();                                        // whoever used the LDS before is done with it
+            issue(0, 0);
+            for (int k0 = 0, buf = 0; k0 < K; k0 += GD_KC, buf ^= 1) {
+                __syncthreads();                                    // chunk k0 has landed (hipcc drains the DMAs in front of the barrier); buffer buf ^ 1 is free
+                if (k0 + GD_KC < K) issue(k0 + GD_KC, buf ^ 1);
+                const double* const As = lds + buf * GD_BUF + fragA;
+                const double* const Bs = lds + (2 + buf) * GD_BUF + fragB;
+                // The tiles of this wave one after the other, reads and MFMAs alternating in pairs of k-steps.  Measured
+                // (scripts/probe/probe14.hip, profiles/r04_probe14_gemm_inner_loop.log): one wave issues an fp64 16x16x4 MFMA per
+                // 64 cycles and nothing else meanwhile; two waves of a SIMD reach one per 32 only with operands in registers --
+                // fed from LDS their read phases and MFMA phases take turns and the SIMD settles at one MFMA per 64 cycles
+                // whatever the order.  Tried in this loop and measured slower: the fragments of tile q + 1 requested ahead of
+                // tile q's MFMAs (+19 %), all of a k-step's fragments first and then its 13 MFMAs (+18 %), four reads and four
+                // MFMAs per tile in straight-line code (+11 %).
+#pragma unroll
+                for (int q = 0; q < G_TPW; ++q) {
+                    const int e = wave + NWAVE * q;
+                    if (e < T) {
+                        const int ti = e / nt, tj = e - ti * nt;
+                        const double* const ap = As + tileA * ti;
+                        const double* const bp = Bs + tileB * tj;
+#pragma unroll
+                        for (int kq = 0; kq < GD_KC / 4; ++kq)
+                            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[stepA * kq], bp[stepB * kq], acc[q], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < G_TPW; ++q) {
+                const int e = wave + NWAVE * q;
+                if (e < T) {
+                    const int ti = e / nt, tj = e - ti * nt;
+                    const int j = j0 + 16 * tj + lo;
+                    double ev[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int ii = i0 + 16 * ti + 4 * v + hi;
+                        ev[v] = (E && ii < M && j < N) ? E[ii * lde + j] : 0.0;
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int ii = i0 + 16 * ti + 4 * v + hi;
+                        if (ii < M && j < N) C[ii * ldc + j] = fma(ce, ev[v], cab * acc[q][v]);
+                    }
+                }
+            }
+        }
+    __syncthreads();
+}
+
+__device__ __noinline__ void wg_gemm(const GemmOp& g_) {
+    const GemmOp& gr = *uni(&g_);
+    const int K = uni(gr.K), lda = uni(gr.lda), ldb = uni(gr.ldb);
+    const unsigned long long pa = uni_bits(gr.A), pb = uni_bits(gr.B);
+    if ((K & (GD_KC - 1)) != 0 || ((lda | ldb) & 1) != 0 || ((pa | pb) & 15) != 0) { wg_gemm_staged(g_); return; }
+    auto* const C = uni_g(gr.C);
+    auto* const A = uni_g(gr.A);
+    auto* const B = uni_g(gr.B);
+    auto* const E = uni_g(gr.E);
+    const int ldc = uni(gr.ldc), M = uni(gr.M), N = uni(gr.N), lde = uni(gr.lde);
+    const double ce = uni(gr.ce), cab = uni(gr.cab);
+    const bool ta = uni((int)gr.ta) != 0, tb = uni((int)gr.tb) != 0;
+    // A given transposed (K x M): its rows run along k; B given as is (K x N): likewise
+    if (ta) { if (!tb) wg_gemm_dma_body<true, true>(C, ldc, A, lda, B, ldb, M, N, K, E, lde, ce, cab);
+              else wg_gemm_dma_body<true, false>(C, ldc, A, lda, B, ldb, M, N, K, E, lde, ce, cab); }
+    else    { if (!tb) wg_gemm_dma_body<false, true>(C, ldc, A, lda, B, ldb, M, N, K, E, lde, ce, cab);
+              else wg_gemm_dma_body<false, false>(C, ldc, A, lda, B, ldb, M, N, K, E, lde, ce, cab); }
 }
 
 // y (M) = ce * e + cab * op(A) x ; A (M x K) or, if TA, A is (K x M) and op(A) = A^T
@@ -553,45 +688,54 @@ __device__ __noinline__ void lu_rank_update(int lp_off, int lrows_, int nb_, int
     }
 }
 
-// x <- E11^{-1} x for ONE right-hand-side column and a 16 x 16 triangular block E11 whose row j lies in LDS at
-// prow0[j * LU_LD + 0 .. 15] (every thread reads the same addresses: broadcasts).  LOWER: forward substitution from row 0,
-// else back substitution from row 15; UNIT: unit diagonal (the L of the LU), else x_j is scaled by rdiag[j] = 1 / e_jj.
-// Entries of x from nb on are zero on entry and on exit; columns >= nb of the staged block are zero or meet those zeros.
-// The substitution is a dependent chain, so what matters is what sits ON the chain: each row's block entries are read one
-// row AHEAD (tied by an empty asm to the result two rows back, so that hipcc neither issues all 120 reads up front -- they
-// spill -- nor waits for every single read, which is what a branch per entry made of the first version: 750 cycles per
-// row), and a row's sum runs in two independent accumulators.
+// x <- E11^{-1} x for ONE right-hand-side column per lane and a 16 x 16 triangular block E11 whose row j lies in LDS at
+// prow0[j * LU_LD + 0 .. 15].  LOWER: forward substitution from row 0, else back substitution from row 15; UNIT: unit diagonal
+// (the L of the LU), else x_j is scaled by rdiag[j] = 1 / e_jj.  Entries of x from nb on are zero on entry and on exit; columns
+// >= nb of the staged block are zero or meet those zeros.
+// Round 4: the 16 lanes of a DPP row share the block -- lane i keeps COLUMN i of it (16 registers, 16 LDS reads), and
+// E[j][i] reaches the whole row inside the FMA (v_fmac_f64_dpp ... row_newbcast:i, the one 64-bit DPP form gfx90a+ has).  The
+// first version read every entry as an LDS broadcast, one row ahead of the chain: 120 reads per column and ~5 k cycles per
+// block (stamps of round 4); terms and their order are unchanged (even i into s0, odd i into s1, s0 + s1), so are the bits.
+// Every 16-lane row that takes part must be entirely active (all call sites cut their column ranges at multiples of 16).
+template <int I>
+__device__ __forceinline__ void dense_fnmac_bc(double& acc, double e, double y) {       // acc -= e(lane I of the row) * y
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(e), "v"(y), "n"(I));
+}
+template <bool LOWER, int J, int I>
+__device__ __forceinline__ void trsm16_row(double& s0, double& s1, const double (&x)[LU_NB], double ej) {
+    if constexpr (I < LU_NB) {
+        if constexpr (LOWER ? I < J : I > J) {
+            if constexpr (I & 1) dense_fnmac_bc<I>(s1, ej, x[I]);
+            else dense_fnmac_bc<I>(s0, ej, x[I]);
+        }
+        trsm16_row<LOWER, J, I + 1>(s0, s1, x, ej);
+    }
+}
+template <bool LOWER, bool UNIT, int STEP>
+__device__ __forceinline__ void trsm16_steps(double (&x)[LU_NB], double (&er)[LU_NB], int nb, const double* rdiag) {
+    if constexpr (STEP < LU_NB) {
+        constexpr int J = LOWER ? STEP : LU_NB - 1 - STEP;
+        double s0 = x[J], s1 = 0.0;
+        trsm16_row<LOWER, J, 0>(s0, s1, x, er[J]);
+        const double sacc = s0 + s1;
+        x[J] = J < nb ? (UNIT ? sacc : sacc * rdiag[J]) : 0.0;
+        trsm16_steps<LOWER, UNIT, STEP + 1>(x, er, nb, rdiag);
+    }
+}
 template <bool LOWER, bool UNIT>
 __device__ __forceinline__ void trsm16(double (&x)[LU_NB], const double* prow0, int nb, const double* rdiag) {
-    double rowv[2][LU_NB];
-    auto row_of = [](int step) { return LOWER ? step : LU_NB - 1 - step; };
-    auto load_row = [&](int step, int off) {
-        const int j = row_of(step);
-        const double* const pr = prow0 + j * LU_LD + off;
+    double er[LU_NB];
+    const int li = threadIdx.x & 15;
 #pragma unroll
-        for (int i = 0; i < LU_NB; ++i)
-            if (LOWER ? i < j : i > j) rowv[step & 1][i] = pr[i];
-    };
-    load_row(0, 0);
-    load_row(1, 0);
+    for (int j = 0; j < LU_NB; ++j) er[j] = prow0[j * LU_LD + li];
+    // (a VALU write of a VGPR needs two wait states before a DPP operand reads it; the block entries come from LDS, this
+    //  keeps their loads and whatever the compiler does to them in front of the chain)
 #pragma unroll
-    for (int step = 0; step < LU_NB; ++step) {
-        const int j = row_of(step);
-        double s0 = x[j], s1 = 0.0;
+    for (int j = 0; j < LU_NB; ++j) asm volatile("" : "+v"(er[j]));
+    asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < LU_NB; ++i)
-            if (LOWER ? i < j : i > j) {
-                if (i & 1) s1 = fma(-rowv[step & 1][i], x[i], s1);
-                else s0 = fma(-rowv[step & 1][i], x[i], s0);
-            }
-        const double sacc = s0 + s1;
-        x[j] = j < nb ? (UNIT ? sacc : sacc * rdiag[j]) : 0.0;
-        if (step + 2 < LU_NB) {
-            int off = 0;
-            asm("" : "+v"(off) : "v"(x[j]));                         // row step + 2 is read once row step is done
-            load_row(step + 2, off);
-        }
-    }
+    for (int j = 0; j < LU_NB; ++j) asm volatile("" : "+v"(er[j]));
+    trsm16_steps<LOWER, UNIT, 0>(x, er, nb, rdiag);
 }
 
 // Net row permutation of one panel applied to `ncols` columns of M (row stride ld, rows relative to k0): one thread
@@ -670,8 +814,14 @@ template <bool LOWER>
 __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int trans_, double* Bm_, int ldb_, int n_, int nr_,
                                                double* ws_end_ = nullptr);
 
+}  // namespace rk
+#include "solve_dense_lu_regs.hpp"
+namespace rk {
+
+// regs_: the forward elimination with [A | Bm] resident in registers (solve_dense_lu_regs.hpp) where the sizes allow it;
+// 0 = always the panel loop over global memory below (RK_DENSE_LU=global: the bit-equality test's other leg)
 __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int ldb_, int n_, int nr_, int* piv_,
-                                         double* ws_end_ = nullptr) {
+                                         double* ws_end_ = nullptr, int regs_ = 1) {
     double* const lds = g_lds;
     auto* const A = uni_g(A_);
     auto* const Bm = uni_g(Bm_);
@@ -680,6 +830,14 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
     (void)ws_end;
     const int lda = uni(lda_), ldb = uni(ldb_), n = uni(n_), nr = uni(nr_);
     RK_STAMP_DECL(ws_end);
+    if (uni(regs_) != 0 && n > 64 && n <= RL_N && nr <= RL_N && DT == 512) {
+        RK_STAMP_RESET();
+        wg_lu_fwd_regs((double*)A, lda, (double*)Bm, ldb, n, nr, (double*)ws_end);
+        RK_STAMP_RESET();
+        wg_tri_solve_regs<false>((const double*)A, lda, 0, (double*)Bm, ldb, n, nr);
+        RK_STAMP(5);
+        return;
+    }
     const int nrp = (n + 15) & ~15, nbp = (nr + 15) & ~15;      // strip: [0, nrt) trailing columns, [nrt, nrt + nbp) right-hand sides
     const int usp = (nrp + nbp + 16) | 1;                       // odd row stride
     if (n > LU_MAXN || n * LU_LD + LU_NB * usp > LDS_DOUBLES) { wg_lu_solve_unblocked(lds, (double*)A, lda, (double*)Bm, ldb, n, nr, (int*)piv); return; }
@@ -833,7 +991,7 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
                     lu_rank_update(poff + nb * LU_LD, n_right, nb, us_off + ca, usp, rt, A22 + ca, lda, nAc, a1 - a0,
                                    B2 + cb, ldb, nBc, b1 - b0, nrt + cb - ca, n_right, wave, 1);
                 }
-                if (wave == 1) RK_WSTAMP(6, tw0_);                     // (stamps build: wave 1's whole strip)
+                if (wave == 1) RK_WSTAMP(5, tw0_);                     // (stamps build: wave 1's whole strip)
             }
 #undef RK_WSTAMP
         } else {
@@ -859,8 +1017,8 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         RK_STAMP(4);
     }
     if (n > 64 && n <= 16 * BS_T && nr <= 16 * BS_T && DT == 512) {     // right-hand side resident in registers
-        wg_tri_solve_regs<false>((const double*)A, lda, 0, (double*)Bm, ldb, n, nr);
-        RK_STAMP(5);
+        wg_tri_solve_regs<false>((const double*)A, lda, 0, (double*)Bm, ldb, n, nr, (double*)ws_end);
+        RK_STAMP_RESET();
         return;
     }
     // back substitution with U, block rows from the bottom
@@ -1053,6 +1211,89 @@ __device__ __noinline__ void wg_bd_right(double* C_, const double* X_, const dou
     __syncthreads();
 }
 
+// Round 4: the whole block-diagonal predict in ONE pass.  With Q = blockdiag(Q_I) the nd x nd block (I, J) of
+//   Sigma^- = (Q Sigma) Q^T + R          is   (Q_I Sigma_IJ) Q_J^T + R_IJ                      (standard.py:58-59)
+//   T^T = Q Sigma_f^T   (standard.py:175) is   Q_I (Sigma_f,JI)^T
+// -- a function of ONE block of Sigma (and of its mirror image for T^T): a thread loads block (I, J) [and (J, I)], forms both
+// products in registers with the terms and the order of wg_bd_left / wg_bd_right (k ascending into s = 0, then e + s), and
+// stores Sigma^-, T^T and D = F - Sigma^- (the Sigma_next - Sigma^- of standard.py:215).  No intermediate Q Sigma in memory
+// (the two-pass form wrote and re-read it: 0.4 MB per step) and no transposed read: the mirror block's rows are as
+// contiguous as the block's own.  Lanes run along J: a wave's five loads of a block row cover 64 x 40 contiguous bytes.
+// C2 = null: only Sigma^- (the forward pass); D = null: no difference.
+template <int ND>
+__device__ __forceinline__ void wg_bd_predict_nd(gd* C, gd* C2, gd* D, cgd* X, cgd* E, cgd* F, int p) {
+    const double* const qd = g_qd;
+    const int nblk = p / ND, total = nblk * nblk;
+    for (int e = threadIdx.x; e < total; e += DT) {
+        const int ib = e / nblk, jb = e - ib * nblk, i0 = ib * ND, j0 = jb * ND;
+        // (block, mirror block) -> (Q_I x, Q_I xm^T) first, the additive terms row by row afterwards: all six 5 x 5 blocks at
+        //  once are 300 registers (the first version spilled and ran slower than the two passes)
+        double y[ND][ND], yt[ND][ND];
+        {
+            double x[ND][ND], xm[ND][ND];
+#pragma unroll
+            for (int r = 0; r < ND; ++r)
+#pragma unroll
+                for (int c = 0; c < ND; ++c) {
+                    x[r][c] = X[(i0 + r) * p + j0 + c];
+                    if (C2) xm[r][c] = X[(j0 + r) * p + i0 + c];     // block (J, I): xm[r][c] = Sigma[j0 + r][i0 + c]
+                }
+            // y = Q_I x (k ascending, like wg_bd_left); yt = Q_I xm^T
+#pragma unroll
+            for (int r = 0; r < ND; ++r)
+#pragma unroll
+                for (int c = 0; c < ND; ++c) {
+                    double s_ = 0.0, st = 0.0;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) {
+                        s_ = fma(qd[(i0 + r) * BD_MAX + k], x[k][c], s_);
+                        if (C2) st = fma(qd[(i0 + r) * BD_MAX + k], xm[c][k], st);
+                    }
+                    y[r][c] = s_;
+                    yt[r][c] = st;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < ND; ++r) {
+            double ev[ND], fv[ND];
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                ev[c] = E[(i0 + r) * p + j0 + c];
+                if (D) fv[c] = F[(i0 + r) * p + j0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                double s_ = 0.0;
+#pragma unroll
+                for (int k = 0; k < ND; ++k) s_ = fma(y[r][k], qd[(j0 + c) * BD_MAX + k], s_);     // (like wg_bd_right)
+                const double cv = ev[c] + s_;
+                C[(i0 + r) * p + j0 + c] = cv;
+                if (C2) C2[(i0 + r) * p + j0 + c] = yt[r][c];
+                if (D) D[(i0 + r) * p + j0 + c] = fv[c] - cv;
+            }
+        }
+    }
+    __syncthreads();
+}
+// returns false if nd has no instance (the caller then runs the two passes)
+__device__ __noinline__ bool wg_bd_predict(double* C_, double* C2_, double* D_, const double* X_, const double* E_, const double* F_,
+                                           int p_, int nd_) {
+    auto* const C = uni_g(C_);
+    auto* const C2 = uni_g(C2_);
+    auto* const D = uni_g(D_);
+    auto* const X = uni_g(X_);
+    auto* const E = uni_g(E_);
+    auto* const F = uni_g(F_);
+    const int p = uni(p_), nd = uni(nd_);
+    switch (nd) {
+        case 2: wg_bd_predict_nd<2>(C, C2, D, X, E, F, p); return true;
+        case 3: wg_bd_predict_nd<3>(C, C2, D, X, E, F, p); return true;
+        case 4: wg_bd_predict_nd<4>(C, C2, D, X, E, F, p); return true;
+        case 5: wg_bd_predict_nd<5>(C, C2, D, X, E, F, p); return true;
+        default: return false;
+    }
+}
+
 // 1.0 if every entry of Q (p x p) outside the nd x nd diagonal blocks is exactly zero, else 0.0
 __global__ void dense_qcheck_kernel(const double* Q, int p, int nd, double* flag) {
     __shared__ int bad;
@@ -1135,17 +1376,22 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
         const double* Sig = var + (size_t)n * p * p;
         double* mu_o = mean + (size_t)(n + 1) * p;
         double* Sig_o = var + (size_t)(n + 1) * p * p;
+        bool fused = false;
 #pragma unroll 1
         for (int ph = decltype(ph_lo)::value; ph < decltype(ph_hi)::value; ++ph) {       // (ONE wg_gemm call site: not unrolled)
             GemmOp g;
             bool run = true;
             switch (ph) {
                 case 0:
-                    if (q_bd) { wg_bd_left(w.A1, Sig, nullptr, nullptr, p, nd); run = false; }
+                    if (q_bd) {
+                        fused = wg_bd_predict(w.A2, nullptr, nullptr, Sig, a.R, nullptr, p, nd);      // (Q Sigma) Q^T + R in one pass
+                        if (!fused) wg_bd_left(w.A1, Sig, nullptr, nullptr, p, nd);
+                        run = false;
+                    }
                     else g = gemm_op(w.A1, p, a.Q, p, false, Sig, p, false, p, p, p, nullptr, 0, 0.0, 1.0);
                     break;
                 case 1:
-                    if (q_bd) { wg_bd_right(w.A2, w.A1, a.R, nullptr, nullptr, p, nd); run = false; }
+                    if (q_bd) { if (!fused) wg_bd_right(w.A2, w.A1, a.R, nullptr, nullptr, p, nd); run = false; }
                     else g = gemm_op(w.A2, p, w.A1, p, false, a.Q, p, true, p, p, p, a.R, p, 1.0, 1.0);
                     break;
                 case 2:
@@ -1265,16 +1511,22 @@ __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
         const double* Sig_s = var + (size_t)(n + 1) * p * p;
         // phases 0-2: pred[n+1] re-evaluated from filt[n], T^T = Q Sigma_f^T (standard.py:175), the differences;
         // 3: G^T = solve(Sigma-, T^T) (standard.py:176), mean (213-214), G D; 4: Sigma_f + (G D) G^T (215-216)
+        bool fused = false;
         for (int ph = 0; ph < 5; ++ph) {
             GemmOp g;
             bool run = true;
             switch (ph) {
                 case 0:
-                    if (q_bd) { wg_bd_left(w.A1, Sig_f, w.A3, Sig_f, p, nd); run = false; }
+                    if (q_bd) {
+                        fused = wg_bd_predict(w.A2, w.A3, w.A4, Sig_f, a.R, Sig_s, p, nd);       // Sigma^-, T^T, Sigma_next - Sigma^- in one pass
+                        if (!fused) wg_bd_left(w.A1, Sig_f, w.A3, Sig_f, p, nd);
+                        run = false;
+                        RK_STAMP(6);
+                    }
                     else g = gemm_op(w.A1, p, a.Q, p, false, Sig_f, p, false, p, p, p, nullptr, 0, 0.0, 1.0);
                     break;
                 case 1:
-                    if (q_bd) { wg_bd_right(w.A2, w.A1, a.R, w.A4, Sig_s, p, nd); run = false; }
+                    if (q_bd) { if (!fused) wg_bd_right(w.A2, w.A1, a.R, w.A4, Sig_s, p, nd); run = false; }
                     else g = gemm_op(w.A2, p, w.A1, p, false, a.Q, p, true, p, p, p, a.R, p, 1.0, 1.0);
                     break;
                 case 2:
@@ -1289,7 +1541,7 @@ __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
                     for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = mu_s[i] - w.mup[i];
                     __syncthreads();
                     RK_STAMP(0);
-                    wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv, a.ws + a.ws_stride);   // A3 <- G^T
+                    wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv, a.ws + a.ws_stride, a.lu_regs);   // A3 <- G^T
                     RK_STAMP_RESET();
                     // mean: mu_f + G dm, the column sums of G^T split over the workgroup (partial sums through LDS)
                     {
@@ -1353,8 +1605,10 @@ __global__ void __launch_bounds__(DT) dense_bwd_sim_kernel(DenseArgs a) {
         const double* Sig_f = var + (size_t)n * p * p;
         // pred[n+1] from filt[n]; T^T = Q Sigma_f^T (standard.py:175)
         if (q_bd) {
-            wg_bd_left(w.A1, Sig_f, w.A3, Sig_f, p, nd);
-            wg_bd_right(w.A2, w.A1, a.R, nullptr, nullptr, p, nd);
+            if (!wg_bd_predict(w.A2, w.A3, nullptr, Sig_f, a.R, nullptr, p, nd)) {
+                wg_bd_left(w.A1, Sig_f, w.A3, Sig_f, p, nd);
+                wg_bd_right(w.A2, w.A1, a.R, nullptr, nullptr, p, nd);
+            }
         } else {
             wg_gemm(gemm_op(w.A1, p, a.Q, p, false, Sig_f, p, false, p, p, p, nullptr, 0, 0.0, 1.0));
             wg_gemm(gemm_op(w.A2, p, w.A1, p, false, a.Q, p, true, p, p, p, a.R, p, 1.0, 1.0));
@@ -1366,7 +1620,7 @@ __global__ void __launch_bounds__(DT) dense_bwd_sim_kernel(DenseArgs a) {
         for (int e = threadIdx.x; e < p * p; e += DT) w.A4[e] = w.A3[e];          // keep T^T: the solve overwrites A3
         for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = w.dm[i] - w.mup[i];   // x_{n+1} - mu-
         __syncthreads();
-        wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv, a.ws + a.ws_stride);           // A3 <- G^T (standard.py:176)
+        wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv, a.ws + a.ws_stride, a.lu_regs);           // A3 <- G^T (standard.py:176)
         // mean_sim = mu_f + G (x_{n+1} - mu-) (standard.py:250-251): column sums of G^T through LDS, as in the smoother
         {
             const int ng = DT / 64;
@@ -1476,6 +1730,10 @@ int dense_solve(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
                "RK_FLAG_STORE_PRED needs out->mean_pred / var_pred");
     RK_REQUIRE(mode != RK_MODE_SIM || out->x_state, RK_ERR_INVALID, "rk_solve_sim needs out->x_state");
     a.fac_pred = nullptr;
+    {
+        const char* const lm = getenv("RK_DENSE_LU");          // "regs": the register-resident forward elimination (solve_dense_lu_regs.hpp)
+        a.lu_regs = lm && lm[0] == 'r';
+    }
     if (c->kalman_type == RK_KALMAN_SQRT) {
         // ---- square-root form (solve_dense_sqrt.hpp) ----
         a.ws_stride = dense_sq_ws_doubles(a.p, a.m);

@@ -110,8 +110,9 @@ def c5(args):
         print("fwd phase cycles per step (wg 0):", {k: int(v) for k, v in zip(names, ws[0, -2:-9:-1] / N)}, file=sys.stderr)
     elif os.environ.get("RK_DENSE_STAMPS"):
         ws = plan._ws.to_host().reshape(B, -1)
-        names = ["predict+T+diff", "LU panel", "LU swaps", "LU trsm", "LU gemm", "back trsm", "back gemm", "mean", "G D", "GDG^T"]
-        cyc = ws[0, -2:-12:-1] / (N - 1)            # library built with -DRK_DENSE_STAMPS (solve_dense.hip)
+        names = ["predict: rest", "LU panel", "LU swaps / gather", "LU trsm", "LU gemm", "LU: wave 1 strips", "predict: fused pass", "mean", "G D", "GDG^T",
+                 "backsub: store", "backsub: stage", "backsub: trsm", "backsub: update"]
+        cyc = ws[0, -2:-16:-1] / (N - 1)            # library built with -DRK_DENSE_STAMPS (solve_dense.hip)
         print("bwd phase cycles per step (wg 0):", {k: int(v) for k, v in zip(names, cyc)}, "total", int(cyc.sum()), file=sys.stderr)
     err = None
     if args.c5_check:                                   # distance of trajectory 0's solution estimate from expm(A t) x0 at the last step

@@ -386,3 +386,30 @@ def test_dense_solve_filter_returns_the_predictions(ra):
             assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :] + 1e-300)) < 1e-6, k
             np.testing.assert_array_equal(m[:, 0], x0)
             assert np.all(v[:, 0] == 0)
+
+
+@pytest.mark.parametrize("n_vars,n_deriv,mode", [(32, 5, "mv"), (20, 5, "mv"), (26, 3, "mv"), (17, 4, "mv"), (13, 5, "sim"),
+                                                  (14, 5, "mv")])
+def test_dense_lu_register_resident_equals_panel_loop(ra, n_vars, n_deriv, mode, monkeypatch):
+    """The register-resident forward elimination (solve_dense_lu_regs.hpp: [Sigma- | T^T] in the registers of the eight
+    waves, pivoting without row movement) replaces the panel loop over global memory of wg_lu_solve with the SAME
+    operations in the same order -- same pivots (LAPACK's, ties included), same substitutions, same four MFMAs per tile --
+    so the smoothed moments must have the same BITS (p = 160, 100, 78, 68, 65 [, 70: n_bstate <= 64 keeps the old
+    path, both legs equal trivially]; RK_DENSE_LU=global selects the panel loop)."""
+    N, B = 6, 5
+    t_max = N / 24.0
+    s = dense_problem(ra, n_vars, n_deriv, N, t_max, B=B, seed=n_vars)
+    ode_d = ra.ode.linear_dense(n_vars, n_deriv)
+    out = {}
+    for leg in ("regs", "global"):
+        monkeypatch.setenv("RK_DENSE_LU", leg)
+        plan = ra.SolvePlan(ode_d, s["W"], s["x0"], 0.0, t_max, N, ra.interrogate.interrogate_rodeo, s["prior"], A=s["A"])
+        if mode == "mv":
+            plan.mv(None)
+            out[leg] = plan.state_host()
+        else:
+            plan.sim(7)
+            out[leg] = (np.array(plan.x_host()),)
+    for a_, b_ in zip(out["regs"], out["global"]):
+        assert np.all(np.isfinite(a_))
+        np.testing.assert_array_equal(a_, b_)
