@@ -216,6 +216,17 @@ int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n
                          int32_t n_obs, double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
                          double* logpost);
 
+/* rk_solve_sim followed by rk_gauss_obs_logpost on its sample path, as ONE call: the body of the user-level log-posterior of
+ * docs/examples/parameter.md:331-354 (constrain -> solve_sim with interrogate_chkrebtii -> Gaussian observation
+ * log-likelihood at searchsorted indices + normal log-prior), what a pseudo-marginal sampler evaluates once per proposal
+ * (src/rodeo/inference/pseudo_marginal.py:135-149).  On the n_bstate = 3 tile path with n_block in {1, 2, 4} the backward
+ * sampler reduces the log-posterior itself (no second launch) and out->x_state may be NULL: then no path is stored at
+ * all and logpost (B) is the only result.  Any other configuration runs the two kernels back to back and needs x_state.
+ * upars / obs / obs_ind must be on the device BEFORE the call (upload them before launching, not between the launches).  */
+int rk_solve_sim_logpost(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
+                         const double* obs, const int32_t* obs_ind, int32_t n_obs, double noise_sd,
+                         const double* upars, int32_t n_prior, double prior_sd, double* logpost);
+
 /* Fenrir's backward pass (src/rodeo/inference/fenrir.py:86-259; the forward pass is rk_solve_filter with the same
  * cfg / in, fenrir.py:304-313): log p(y_{0:M} | Z_{1:N}) per trajectory from the filter's output in `out` -- either
  * the RK_LAYOUT_TILE3 tiles (no flags; predicted moments are re-evaluated on the fly; n_bobs = 1) or the RK_LAYOUT_TILE4 /

@@ -91,6 +91,8 @@ SIGNATURES = {
     "rk_solve_mv": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut)]),
     "rk_solve_sim": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut)]),
     "rk_gauss_obs_logpost": (C.c_int, [_H, _I, _I, _I, _I, _I, _P, _P, _P, _I, _D, _P, _I, _D, _P]),
+    "rk_solve_sim_logpost": (C.c_int, [_H, C.POINTER(SolveCfg), C.POINTER(SolveIn), C.POINTER(SolveOut), _P, _P, _I, _D, _P, _I,
+                                       _D, _P]),
     "rk_fenrir_backward": (C.c_int, [_H, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "rk_fenrir_workspace_bytes": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
     "rk_fenrir_solve_mv": (C.c_int, [_H, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -592,7 +592,12 @@ size_t tilen_ws_doubles(const rk_solve_cfg* c, int mode);
 
 // MFMA-tile path (solve_tile3.hip)
 bool tile3_supported(const rk_solve_cfg* c, int mode);
-int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode);
+struct SimLogpost;
+int tile3_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, int mode, const SimLogpost* lp = nullptr);
+bool tile3_sim_logpost_supported(const rk_solve_cfg* c, int n_obs);
+int tile3_solve_sim_logpost(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* tiles, const double* obs,
+                            const int32_t* obs_ind, int n_obs, double noise_sd, const double* upars, int n_prior, double prior_sd,
+                            double* logpost);
 int tile3_fenrir_backward(rk_handle h, const SolveArgs& a, const double* tiles, const double* obs, const double* obs_w,
                           const double* obs_v, const int32_t* obs_ind, int n_obs, double* logdens);
 
@@ -697,6 +702,41 @@ int rk_solve_mv(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const
 }
 int rk_solve_sim(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out) {
     return solve_common(h, c, in, out, 2);
+}
+
+int rk_gauss_obs_logpost(rk_handle h, int32_t n_traj, int32_t n_steps, int32_t n_block, int32_t n_bstate,
+                         int32_t layout, const double* x_state, const double* obs, const int32_t* obs_ind,
+                         int32_t n_obs, double noise_sd, const double* upars, int32_t n_prior, double prior_sd,
+                         double* logpost);
+
+int rk_solve_sim_logpost(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out,
+                         const double* obs, const int32_t* obs_ind, int32_t n_obs, double noise_sd,
+                         const double* upars, int32_t n_prior, double prior_sd, double* logpost) {
+    RK_REQUIRE(h, RK_ERR_INVALID, "null handle");
+    RK_REQUIRE(obs && obs_ind && logpost && n_obs >= 0, RK_ERR_INVALID, "rk_solve_sim_logpost: null obs / obs_ind / logpost");
+    RK_REQUIRE(!upars || n_prior >= 0, RK_ERR_INVALID, "rk_solve_sim_logpost: n_prior < 0");
+    int rc = check_cfg(c, in);
+    if (rc) return rc;
+    const bool dense = dense_supported(c, 2);
+    if (!dense && !tile4_supported(c, 2) && tile3_sim_logpost_supported(c, n_obs) && c->kalman_type == RK_KALMAN_STANDARD) {
+        // the sampler's consumer wave reduces the log-posterior itself; out->x_state may be NULL (no path is stored)
+        RK_REQUIRE(out && out->var_state, RK_ERR_INVALID, "out->var_state must not be NULL");
+        RK_HIP(hipSetDevice(h->device));
+        if (!h->profile_keep) { h->prof.clear(); h->event_used = 0; }
+        SolveArgs a;
+        make_args(c, in, out, a);
+        return tile3_solve_sim_logpost(h, c, a, out->var_state, obs, obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
+    }
+    // any other configuration: the sampler, then the reduction kernel on its path (one call, no host work in between)
+    RK_REQUIRE(out && out->x_state, RK_ERR_INVALID, "rk_solve_sim_logpost: this configuration needs out->x_state");
+    rc = solve_common(h, c, in, out, 2);
+    if (rc) return rc;
+    const bool keep = h->profile_keep;
+    h->profile_keep = true;                            // (keep the sampler's kernel times next to the reduction's)
+    rc = rk_gauss_obs_logpost(h, c->n_traj, c->n_steps, c->n_block, c->n_bstate, RK_LAYOUT_BATCH_MINOR, out->x_state, obs,
+                              obs_ind, n_obs, noise_sd, upars, n_prior, prior_sd, logpost);
+    h->profile_keep = keep;
+    return rc;
 }
 
 int rk_interrogate_batched(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, double t, int32_t step,

@@ -43,6 +43,16 @@ struct TileWaves {                               // waves per forward workgroup
     static constexpr int value = D <= 4 ? 1 : (D + 3) / 4;
 };
 
+// sqrt(x) for a variance x > 0 in the normal range from v_rsq_f64 and ONE coupled correction: four dependent operations
+// where fast_sqrt_pos (two corrections, <= 1 ulp) has eight -- on the chkrebtii step's chain, whose draw x_0 = mu-_0 +
+// sqrt(Sigma-_00) z_0 is compared at 1e-7 (relative error of this root <= 1e-14: the square of v_rsq_f64's)
+__device__ __forceinline__ double sqrt_pos_1step(double x) {
+    const double rs = __builtin_amdgcn_rsq(x);
+    const double g = x * rs, h = 0.5 * rs;
+    const double s = fma(fma(-g, g, x), h, g);
+    return x > 0.0 ? s : 0.0;
+}
+
 template <class RHS, int ITG>
 __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kernel(SolveArgs a, double* __restrict__ tiles) {
     constexpr int D = RHS::D, P = 3, NW = TileWaves<D>::value, TPW = NW > 1 ? 4 : Tpw<D>::value;
@@ -183,20 +193,31 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
         // measurement row is the constant W and NONE of the step's MFMAs depends on the draw: all seven are issued back to
         // back (U, M-, M-^T, row 0 of M-, Sigma- W^T, W Sigma-, S), and the draw x_0 = mu-_0 + sqrt(Sigma-_00) z_0
         // (interrogate.py:22-34), f(x) and the offset a = -f only touch column 3 of [W Sigma- | W mu- + a] afterwards.
-        // (Tried: a second wave per workgroup that only draws the normals into a double-buffered LDS array -- no gain, the
-        // step is bound by its dependent VALU chain (sqrt, cubic, reciprocal), not by the generator.)
+        // What the step costs (round 4, experiment builds scripts/c4_ablation.sh, C4's 1024 draws x 800 steps): 150 us; without
+        // the Philox / Box-Muller burst every 16 steps 126; without the square root of Sigma-_00 either 103.  Built on that and
+        // measured in round 4, none faster than this kernel: (i) a generator wave per chain wave (two-wave workgroups, and
+        // four-wave workgroups of two chains and two generators, LDS-only barriers, placement primer): 155 / 175 us -- the
+        // generator's fp64 work lands on SIMDs that carry chains; (ii) covariance and mean on separate waves
+        // (interrogate_chkrebtii's gain sequence does not depend on the mean; hand-off of Sigma- W^T, S, Sigma-_00 through LDS,
+        // square roots and reciprocals of a chunk taken off the chain) with and without a third generator wave: each chain
+        // alone steps in ~270 cycles -- the MFMA dependency chain U -> M-^T -> Sigma- W^T -> S plus the reciprocal is the
+        // kramer step's -- and two chains meet on a SIMD: 156-183 us.  Kept: the one-correction square root below.
         double tk[6];
         RHS::tile_consts(blk, th, tk);
         const double ac3 = -tk[1], ac1 = -tk[0], aco = -tk[2], ac0 = -tk[3];      // a = -f as the cubic of the generic path's row 3
         const double e3c = c == 3 ? 1.0 : 0.0;
         for (int n = 0; n < a.N; ++n) {
             // z_0 of this step first: its LDS latency hides behind the MFMAs
+#if defined(RK_T3_ABLATE) && RK_T3_ABLATE >= 1            // experiment builds (scripts/c4_ablation.sh): no generator
+            const double zn = 0.25;
+#else
             if ((n & 15) == 0) {                            // the 16 lanes of a tile draw z_0 for 16 consecutive steps
                 double z0, z1;
                 normal_pair(a.seed, traj, (uint32_t)(n + r * 4 + c), (uint32_t)blk, PURPOSE_INTERROGATE, 0u, z0, z1);
                 zbuf[tc.g * 16 + r * 4 + c] = z0;
             }
             const double zn = zbuf[tc.g * 16 + (n & 15)];
+#endif
             const double U = MF(M, Qt, 0.0);
             RK_STORE_BEHIND(M, U);
             const double Mp = MF(U, Qt, Rt);
@@ -210,7 +231,11 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             const double rS = fast_rcp_cubic(S);            // (ahead of the draw's chain, which is independent of it: -3 %)
             double r0v = R0;
             asm("" : "+v"(r0v) : "v"(rS));
-            const double v_own = fma(fast_sqrt_pos(quad_bcast0(r0v)), zn, quad_bcast3(r0v));
+#if defined(RK_T3_ABLATE) && RK_T3_ABLATE >= 2            // ... and no square root
+            const double v_own = fma(quad_bcast0(r0v), zn, quad_bcast3(r0v));
+#else
+            const double v_own = fma(sqrt_pos_1step(quad_bcast0(r0v)), zn, quad_bcast3(r0v));
+#endif
             const double v_oth = pair_other_quad_uniform(v_own);
             const double am = fma(fma(fma(ac3, v_own, 0.0), v_own, ac1), v_own, fma(aco, v_oth, ac0));     // mean_meas = -f(x, t)
             const double WS = fma(e3c, am, WS0);            // yhat = W mu- + a in column 3         (standard.py:93)

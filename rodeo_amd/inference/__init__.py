@@ -6,6 +6,6 @@ kernels of src/rodeo/inference/pseudo_marginal.py for many chains in lock-step (
 ``fenrir``: the Fenrir likelihood (src/rodeo/inference/fenrir.py:261-327, "next-4").  dalton / magi are out of scope.
 """
 from .basic import basic
-from .logpost import gauss_obs_logpost, obs_index
+from .logpost import gauss_obs_logpost, obs_index, sim_logpost, stage_upars
 from . import pseudo_marginal
 from .fenrir import fenrir

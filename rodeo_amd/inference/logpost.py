@@ -77,3 +77,86 @@ def gauss_obs_logpost(plan, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10
                                             d_ind.ptr, ind.shape[0], float(noise_sd),
                                             d_up.ptr if d_up is not None else None, k, float(prior_sd), out.ptr))
     return out
+
+
+def _staged(plan, obs_data, obs_ind, upars, n_prior):
+    """Device copies of the observations / indices (cached on the plan while unchanged) and of the transposed parameters."""
+    dev = plan.dev
+    obs = np.ascontiguousarray(obs_data, dtype=np.float64)
+    ind = np.ascontiguousarray(obs_ind, dtype=np.int32)
+    if obs.shape != (ind.shape[0], plan.d):
+        raise ValueError(f"obs_data must have shape (n_obs, {plan.d})")
+    if ind.size and (ind.min() < 0 or ind.max() > plan.N):
+        raise ValueError("obs_ind outside the solver grid")
+    cache = plan.__dict__.setdefault("_logpost_cache", {})
+    sig = (obs.shape, obs.tobytes(), ind.tobytes())
+    if cache.get("sig") != sig:
+        cache["sig"], cache["obs"], cache["ind"] = sig, dev.to_device(obs), dev.to_device(ind)
+    d_up, k = None, 0
+    if upars is not None and hasattr(upars, "ptr"):           # already staged: a DeviceArray (n_prior, B) from stage_upars()
+        d_up, k = upars, int(upars.shape[0])
+    elif upars is not None:
+        d_up = stage_upars(plan, upars, n_prior)
+        k = int(d_up.shape[0])
+    return cache, cache["obs"], cache["ind"], ind.shape[0], d_up, k
+
+
+def stage_upars(plan, upars, n_prior=None):
+    """The first ``n_prior`` unconstrained parameters of every trajectory as a device array (n_prior, B), batch-minor: what the
+    reduction reads.  Upload it together with the plan's other inputs (``SolvePlan.update``), BEFORE the kernels are launched."""
+    cache = plan.__dict__.setdefault("_logpost_cache", {})
+    up = np.asarray(upars, dtype=np.float64)
+    k = up.shape[1] if n_prior is None else int(n_prior)
+    upt = np.ascontiguousarray(up[:, :k].T)
+    d_up = cache.get("up")
+    if d_up is None or tuple(d_up.shape) != upt.shape:
+        d_up = cache["up"] = plan.dev.to_device(upt)
+    else:
+        d_up.upload(upt)
+    return d_up
+
+
+def sim_logpost(plan, key, obs_data, obs_ind, noise_sd, upars=None, prior_sd=10.0, n_prior=None, keep_path=False):
+    """
+    ``plan.sim(key)`` followed by ``gauss_obs_logpost`` on its path as ONE device call (``rk_solve_sim_logpost``): the body of
+    the log-posterior of docs/examples/parameter.md:331-354.  Everything the kernels read is uploaded BEFORE the launch (an
+    upload between sampler and reduction left the GPU idle for 30 of C4's 275 us per evaluation); on the n_bstate = 3 tile
+    path the backward sampler reduces the log-posterior itself and, unless ``keep_path``, stores no path at all.
+    Returns a DeviceArray (B,) from a ring of four buffers owned by the plan (overwritten by the fourth call after this one).
+    """
+    from ..solve import _seed
+    dev = plan.dev
+    cache, d_obs, d_ind, n_obs, d_up, k = _staged(plan, obs_data, obs_ind, upars, n_prior)
+    ring = cache.setdefault("out_ring", [])
+    if ring and tuple(ring[0].shape) != (plan.B,):
+        ring.clear()
+        cache["out_calls"] = 0
+    n_call = cache.get("out_calls", 0)
+    cache["out_calls"] = n_call + 1
+    if len(ring) < 4:
+        ring.append(dev.empty((plan.B,)))
+    out = ring[n_call % 4]
+    fused = _fused_supported(plan, n_obs)
+    plan._no_path = fused and not keep_path and plan.x_state is None
+    try:
+        plan.generation += 1
+        plan._prepare_out(_lib.MODE_SIM)
+    finally:
+        plan._no_path = False
+    plan.last_mode = _lib.MODE_SIM
+    plan.cfg.seed = _seed(key)
+    so = plan._out
+    if fused and not keep_path:
+        so = _lib.SolveOut(workspace=so.workspace, workspace_bytes=so.workspace_bytes, mean_state=so.mean_state,
+                           var_state=so.var_state, mean_pred=so.mean_pred, var_pred=so.var_pred, x_state=None)
+    _lib.check(dev.lib.rk_solve_sim_logpost(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(so), d_obs.ptr, d_ind.ptr,
+                                            n_obs, float(noise_sd), d_up.ptr if d_up is not None else None, k,
+                                            float(prior_sd), out.ptr))
+    return out
+
+
+def _fused_supported(plan, n_obs):
+    """Mirror of tile3_sim_logpost_supported (csrc/solve_tile3.hip): the configurations whose sampler reduces the log-posterior."""
+    lay = C.c_int32(0)
+    _lib.check(plan.dev.lib.rk_solve_layout(C.byref(plan.cfg), _lib.MODE_SIM, C.byref(lay)))
+    return lay.value == _lib.LAYOUT_TILE3 and plan.d in (1, 2, 4) and n_obs <= 512 and n_obs * plan.d <= 1024

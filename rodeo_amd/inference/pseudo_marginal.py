@@ -281,15 +281,14 @@ class FitzLogPosterior:
         """The log-posteriors as a DEVICE array of shape (C,) -- what a sharded caller hands to the RCCL all-gather without a
         round trip through the host (``shard.gather_scalars_device``).  One of four buffers of the plan, overwritten by the
         fourth call after this one."""
-        from .logpost import gauss_obs_logpost
+        from .logpost import sim_logpost
         upars = np.asarray(upars, dtype=np.float64)
         if upars.shape != (self.C, 7):
             raise ValueError(f"upars must have shape ({self.C}, 7)")
         theta, x0, prior = self._constrain(upars)
         self.plan.update(ode_init=x0, prior_pars=prior, theta=theta)
-        self.plan.sim(key)
-        return gauss_obs_logpost(self.plan, self.obs, self.ind, self.noise_sd, upars=upars, prior_sd=self.prior_sd,
-                                 n_prior=5, reuse_out=True)
+        # sampler and reduction as one device call (rk_solve_sim_logpost): no path is stored, only C doubles come out
+        return sim_logpost(self.plan, key, self.obs, self.ind, self.noise_sd, upars=upars, prior_sd=self.prior_sd, n_prior=5)
 
     def __call__(self, upars, key):
         return self.device(upars, key).to_host(), None

@@ -185,7 +185,7 @@ class SolvePlan:
                 self.mean_pred, self.var_pred = dev.empty((B, N1, d, p)), dev.empty((B, N1, d, p, p))
             else:
                 self.mean_pred, self.var_pred = dev.empty((N1, d, p, B)), dev.empty((N1, d, p, p, B))
-        if mode == _lib.MODE_SIM and self.x_state is None:
+        if mode == _lib.MODE_SIM and self.x_state is None and not getattr(self, "_no_path", False):
             self.x_state = dev.empty((N1, d, p, B))
         wsb = C.c_size_t(0)
         _lib.check(self.dev.lib.rk_solve_workspace_bytes(C.byref(self.cfg), mode, C.byref(wsb)))

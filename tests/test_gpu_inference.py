@@ -115,6 +115,23 @@ def test_chkrebtii_pseudo_marginal_logposterior(ra):
     for k in (1, 2, 3, 4):
         np.testing.assert_array_equal(ring[k].to_host(), want[k])
     np.testing.assert_array_equal(ring[0].to_host(), want[4])              # overwritten by the fifth call, as documented
+    # Sampler and reduction as ONE device call (rk_solve_sim_logpost): the backward sampler's consumer wave adds the observation
+    # terms itself and stores NO path -- same draws (same key), same value up to the order of the sum; observations at the first
+    # and at the last grid point included (x_0 = ode_init, the terminal draw)
+    from rodeo_amd.inference import sim_logpost
+    plan2 = ra.SolvePlan(ra.ode.fitzhugh_nagumo, W, X0, 0., t_max, N, g, prior, theta=theta)
+    lp_f = sim_logpost(plan2, 99, s["Y"], ind, sd, upars=upars, prior_sd=10.0, n_prior=5).to_host()
+    assert plan2.x_state is None                                           # nothing of the path was stored
+    np.testing.assert_allclose(lp_f, lp, rtol=1e-13, atol=1e-10)
+    np.testing.assert_allclose(lp_f, ref, rtol=1e-6, atol=1e-5)
+    ind_e = np.array([0, 3, 3, N // 2, N], dtype=np.int32)                 # ends of the grid, a repeated index
+    Ye = np.random.default_rng(5).standard_normal((5, 2))
+    lp_e = sim_logpost(plan2, 99, Ye, ind_e, sd, upars=None).to_host()
+    ref_e = np.array([np.sum(norm.logpdf(Ye, loc=x[b][ind_e, :, 0], scale=sd)) for b in range(B)])
+    np.testing.assert_allclose(lp_e, ref_e, rtol=1e-12, atol=1e-9)
+    lp_k = sim_logpost(plan2, 99, s["Y"], ind, sd, upars=upars, n_prior=5, keep_path=True).to_host()     # ... and with the path kept
+    np.testing.assert_allclose(lp_k, lp_f, rtol=0, atol=0)
+    np.testing.assert_array_equal(plan2.x_host(), x)
 
 
 def test_lockstep_pseudo_marginal_chain_on_device(ra):
