@@ -31,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# HBM traffic of the two headline kernels from this command's rocprofv3 --pmc passes (scripts/collect_profiles.sh): the
+# committed file `roofline.traffic` is read from -- named, so that counter files of other workloads can never be picked up
+PMC_TRAFFIC_FILE = "r03d_pmc_traffic.json"
 N_STEPS, N_TRAJ, T_MAX, P, D = 4000, 1024, 40.0, 3, 2
 
 
@@ -151,6 +154,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--require-rccl", action="store_true", help="N > 1: exit non-zero if RCCL does not come up on every rank")
     ap.add_argument("--comm", choices=["rccl", "host"], default="rccl", help="N > 1: what carries the barriers")
+    ap.add_argument("--allow-host-fallback", action="store_true",
+                    help="N > 1 on a box with N GPUs: keep going on the host channel when RCCL does not come up (default: exit 3)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # own launcher: N rank processes of this script, started before anything here has touched a GPU
@@ -190,9 +195,14 @@ def main():
             if rccl is not None:
                 comm = "rccl"
             else:
-                print(f"[rank {rank}] RCCL communicator unavailable ({why}); host channel carries the barriers",
-                      file=sys.stderr)
-                if args.require_rccl:
+                # A box with one GPU per rank MUST bring RCCL up: a scaling run that quietly measured the host channel would
+                # be worthless.  The fallback is for the shared-GPU rehearsal only (fewer GPUs than ranks) or on request.
+                enough_gpus = n_dev.value >= world
+                fatal = args.require_rccl or (enough_gpus and not args.allow_host_fallback)
+                print(f"[rank {rank}] RCCL communicator unavailable ({why}); "
+                      + ("exiting with code 3 (--allow-host-fallback to run on the host channel)" if fatal
+                         else "host channel carries the barriers (config.comm = host-tcp)"), file=sys.stderr)
+                if fatal:
                     sys.stdout.flush(); sys.stderr.flush()
                     os._exit(3)            # every rank takes this branch (the outcome was agreed over the host channel)
 
@@ -247,10 +257,10 @@ def main():
         # (not measured by this run: counters need their own rocprofv3 pass -- scripts/collect_profiles.sh; the file is named)
         traffic, traffic_src = None, None
         try:
-            pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
-            if pm:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["kernels"][dom]["hbm_bytes_corrected"]
-                traffic_src = "profiles/" + pm[-1] + " (separate rocprofv3 --pmc passes of this command, committed)"
+            # the file is NAMED (PMC_TRAFFIC_FILE at the top): the newest set of this command's counter passes, not whatever
+            # sorts last among the profiles of other workloads
+            traffic = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))["kernels"][dom]["hbm_bytes_corrected"]
+            traffic_src = "profiles/" + PMC_TRAFFIC_FILE + " (separate rocprofv3 --pmc passes of this command, committed)"
         except Exception:
             traffic, traffic_src = None, None
         out = {

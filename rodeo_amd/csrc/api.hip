@@ -256,9 +256,11 @@ int rk_comm_init(rk_handle h, int rank, int nranks, const void* uid128) {
     RK_HIP(hipSetDevice(h->device));
     ncclUniqueId id;
     memcpy(&id, uid128, sizeof(id));
+    // rk_comm_barrier's word, on h->device -- allocated BEFORE the communicator exists: a failure here must not leave a
+    // communicator behind that neither rk_comm_destroy nor rk_destroy would ever see
+    if (!h->comm_scratch) RK_HIP(hipMalloc((void**)&h->comm_scratch, sizeof(double)));
     ncclComm_t comm;
     RK_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
-    if (!h->comm_scratch) RK_HIP(hipMalloc((void**)&h->comm_scratch, sizeof(double)));      // rk_comm_barrier's word, on h->device
     h->comm = (void*)comm;
     h->rank = rank;
     h->nranks = nranks;

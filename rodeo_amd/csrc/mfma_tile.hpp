@@ -150,6 +150,8 @@ __device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmc
 // accesses, not for its global stores and LDS-DMA loads (__syncthreads() waits vmcnt(0) too: the chain wave then stands at every
 // tick until its own stores of the tick have been written, and a producer until the prefetch it issued for three ticks later
 // has landed).  Nobody in such a kernel reads what another wave stored to global memory.
+// INVARIANT the callers keep (noted at every lds_dma16 call site): an LDS-DMA landing zone is read only by the wave that
+// issued the DMA, behind that wave's own lds_dma_wait_all() -- this barrier does not wait for DMAs in flight.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 }  // namespace rk

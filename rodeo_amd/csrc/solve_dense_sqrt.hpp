@@ -24,6 +24,10 @@
 //   wg_tri_solve   X = E^{-1} B for a triangular E given as a row-major triangle or its transpose, both directions,
 //                  the right-hand side resident in registers (the back substitution of the LU path, generalised).
 //   wg_transpose   dst = src^T through LDS bands (optionally only the upper triangle of src: L = R^T).
+// LAW OF THE SAMPLER (solve_sim in this mode): draws are x = mean + L z, i.e. N(mean, L L^T), L = the conditional factor of
+// square_root.smooth_sim.  The reference passes that factor to jax.random.multivariate_normal(method="svd") in the
+// COVARIANCE slot (src/rodeo/solve.py:179,182-186 with square_root.py:259), i.e. samples N(mean, L): not reproduced (not a law
+// when L is not symmetric PSD; MIGRATION.md).  tests/test_gpu_solver.py::test_square_root_sim_law_is_L_Lt pins it by moments.
 #pragma once
 
 namespace rk {

@@ -9,6 +9,10 @@
 // same): interrogate_rodeo hands W L- W^T and interrogate_chkrebtii hands W L- (1 x p) to the update as the
 // "factor" of var_meas (src/rodeo/interrogate.py:36-42, 110-113).  One quirk is NOT kept: solve_sim's draws use
 // N(mean, L L^T) (the reference passes the factor where jax expects a covariance, solve.py:179).
+// LAW OF THE SAMPLER (solve_sim in this mode): draws are x = mean + L z, i.e. N(mean, L L^T), L = the conditional factor of
+// square_root.smooth_sim.  The reference passes that factor to jax.random.multivariate_normal(method="svd") in the
+// COVARIANCE slot (src/rodeo/solve.py:179,182-186 with square_root.py:259), i.e. samples N(mean, L): not reproduced (not a law
+// when L is not symmetric PSD; MIGRATION.md).  tests/test_gpu_solver.py::test_square_root_sim_law_is_L_Lt pins it by moments.
 #include <cstdlib>
 #include "common.hpp"
 #include "kalman_small.hpp"

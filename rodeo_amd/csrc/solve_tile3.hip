@@ -89,6 +89,7 @@ __device__ __forceinline__ void tile3_gain_producers(const SolveArgs& a, const d
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int n = n_hi - frow[i];                        // rows past the start (n < 1) are clamped, never handed over
+            // (INVARIANT of lds_barrier(): this landing zone is read by the wave that issued the DMA and by no other)
             lds_dma16(wave_tiles + (size_t)(n < 1 ? 1 : n) * tstride * 8 + fcol[i], zone_lds + 1024 * i);
         }
     };
@@ -495,6 +496,7 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int n = n_hi - frow[i];
+                // (INVARIANT of lds_barrier(): this landing zone is read by the wave that issued the DMA and by no other)
                 lds_dma16(wave_tiles + (size_t)(n < 1 ? 1 : n) * tstride * 8 + fcol[i], zone_lds + 1024 * i);
             }
         };

@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
 #pragma unroll
             for (int i = 0; i < N_DMA; ++i) {
                 const int n = n_hi - frow[i];
+                // (INVARIANT of lds_barrier(): this landing zone is read by the wave that issued the DMA and by no other)
                 lds_dma16(wave_rows + (size_t)(n < 1 ? 1 : n) * row_bytes + fcol[i], zone_lds + 1024 * i);
             }
         };
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
             }
 #if RK_T4_STAMPS >= 2
             const long long tB = T4_NOW();
-            __syncthreads();
+            lds_barrier();                                      // (the barrier the shipped kernel uses: the stamps must time ITS waits)
             const long long tC = T4_NOW();
             acc[stg] += tB - tA; acc[3] += tC - tB;
 #else
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
             }
 #ifdef RK_T4_STAMPS
             const long long tB = T4_NOW();
-            __syncthreads();
+            lds_barrier();                                      // (the barrier the shipped kernel uses: the stamps must time ITS waits)
             const long long tC = T4_NOW();
             cacc[0] += tB - tA; cacc[1] += tC - tB;
 #if RK_T4_STAMPS >= 3      // per-tick consumer work of the first 8 workgroups, behind the per-workgroup sums

@@ -190,7 +190,17 @@ class SolvePlan:
         wsb = C.c_size_t(0)
         _lib.check(self.dev.lib.rk_solve_workspace_bytes(C.byref(self.cfg), mode, C.byref(wsb)))
         if wsb.value and (self._ws is None or self._ws.nbytes < wsb.value):
-            self._ws = dev.empty((wsb.value // 8,))
+            try:
+                self._ws = dev.empty((wsb.value // 8,))
+            except Exception:
+                # The records of the square-root small-block path's two-kernel backward pass are OPTIONAL (include/rodeo_kalman.h:
+                # without them the one-kernel form runs, same results, about twice the time) and large -- N d (3 p^2 + p) B
+                # doubles, 13 GB at the headline shape with p = 8.  Every other workspace is required: re-raise.
+                optional = (self.cfg.kalman_type == _lib.KALMAN_SQRT and self.layout == _lib.LAYOUT_BATCH_MINOR and
+                            mode != _lib.MODE_FILTER)
+                if not optional:
+                    raise
+                self._ws = None
         self._out = _lib.SolveOut(
             workspace=self._ws.ptr if self._ws is not None else None,
             workspace_bytes=self._ws.nbytes if self._ws is not None else 0,

@@ -11,7 +11,9 @@ build here and not as a fault on the GPU box:
     kernels listed in SCRATCH_ALLOW with their own bound (runtime-sized local arrays of the unit-parity path);
   * LDS at most 160 KB (MI355X_MICROARCH.md);
   * registers: VGPRs + AGPRs of a kernel fit the waves its own launch bound puts on one SIMD
-    (512 per SIMD lane / ceil(max_flat_workgroup_size / 256) waves).
+    (512 per SIMD lane / ceil(max_flat_workgroup_size / 256) waves);
+  * DPP hazards: the disassembly of every code object goes through scripts/check_dpp_hazards.py (the inline-assembly DPP
+    FMAs of the blocked-tile, dense and LU kernels are invisible to the compiler's own hazard recogniser).
 
     python3 scripts/check_code_objects.py [path/to/librodeo_kalman.so]      exit code 0 = all kernels pass
 """
@@ -21,7 +23,11 @@ import subprocess
 import sys
 import tempfile
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import check_dpp_hazards                                             # noqa: E402
+
 LLVM = os.environ.get("RK_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+DPP_RESULTS = [0, 0]            # DPP instructions scanned / hazards found in the shipped code objects (None: skip the scan)
 SCRATCH_LIMIT = 2048
 SCRATCH_ALLOW = {"kalman_op_kernel": 32768,        # kalman_batched.hip: runtime (n_state <= 16) local matrices, unit-parity ops
                  "13bwd_mv_kernel": 6144,          # solve_small.hip, one lane per (trajectory, block): the p x p register matrices
@@ -49,6 +55,14 @@ def kernels_of(so_path):
                 continue
             txt = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, f)], check=True,
                                  capture_output=True, text=True).stdout
+            if DPP_RESULTS is not None:
+                # inline-assembly DPP operands are invisible to the compiler's hazard recogniser: scan the disassembly of the
+                # SHIPPED code (scripts/check_dpp_hazards.py: VGPR write -> DPP read, VALU write of EXEC -> DPP, labels)
+                dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", os.path.join(tmp, f)],
+                                     check=True, capture_output=True, text=True).stdout
+                n_dpp, n_bad = check_dpp_hazards.scan(dis.splitlines(), f, verbose=True)
+                DPP_RESULTS[0] += n_dpp
+                DPP_RESULTS[1] += n_bad
             for block in re.split(r"\n  - (?=\.agpr_count|\.args)", txt)[1:]:
                 k = {}
                 m = re.search(r"^\s+\.name:\s+(\S+)", block, re.M)
@@ -126,6 +140,10 @@ def main():
         print("check_code_objects: no gfx950 kernels found in", so)
         return 2
     problems = check(ks)
+    if DPP_RESULTS is not None:
+        print(f"check_code_objects: {DPP_RESULTS[0]} DPP instructions in the shipped code objects, {DPP_RESULTS[1]} hazard(s)")
+        if DPP_RESULTS[1]:
+            problems.append(f"{DPP_RESULTS[1]} DPP hazard(s) (VGPR / EXEC write too close in front of a DPP read, see above)")
     worst = max(ks, key=lambda k: k.get("private_segment_fixed_size", 0))
     print(f"check_code_objects: {len(ks)} kernels; largest scratch {worst.get('private_segment_fixed_size', 0)} B "
           f"({demangled(worst['name']).split('(')[0][:60]}); {len(problems)} problem(s)")

@@ -163,3 +163,70 @@ def test_code_objects_fit_their_launch_assumptions():
     for k in ks:
         if any(key in k["name"] for key in cco.MIN_WORKGROUPS_PER_CU):
             assert cco.workgroups_per_cu(k) >= 2, k["name"]
+
+
+def test_dpp_hazard_scanner_rules():
+    """scripts/check_dpp_hazards.py (run over the disassembly of every shipped code object by check_code_objects.py):
+    VGPR write -> DPP read needs two wait states, a VALU write of EXEC five, a branch target resets the history."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_dpp_hazards", os.path.join(ROOT, "scripts", "check_dpp_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dpp = "v_fmac_f64_dpp v[0:1], v[2:3], v[4:5] row_newbcast:1 row_mask:0xf bank_mask:0xf"
+    k = "_ZN2rk1kEv:"
+    cases = [
+        ([k, "v_mul_f64 v[2:3], v[6:7], v[8:9]", dpp], 1),                                  # written right in front
+        ([k, "v_mul_f64 v[2:3], v[6:7], v[8:9]", "s_nop 1", dpp], 0),                       # two wait states
+        ([k, "v_mul_f64 v[2:3], v[6:7], v[8:9]", "v_mov_b32 v9, v10", dpp], 1),             # one instruction is one wait state
+        ([k, "v_mul_f64 v[2:3], v[6:7], v[8:9]", "v_mov_b32 v9, v10", "v_mov_b32 v11, v10", dpp], 0),
+        ([k, "v_mul_f64 v[12:13], v[6:7], v[8:9]", dpp], 0),                                # another register
+        ([k, "v_cmpx_lt_f64 vcc, v[6:7], v[8:9]", "s_nop 2", dpp], 1),                      # EXEC write: three wait states are not five
+        ([k, "v_cmpx_lt_f64 vcc, v[6:7], v[8:9]", "s_nop 4", dpp], 0),
+        ([k, "s_nop 7", ".LBB0_1:", dpp], 1),                                               # a branch target right in front
+        ([k, ".LBB0_1:", "s_nop 1", dpp], 0),
+    ]
+    for lines, want in cases:
+        n, bad = mod.scan(lines, verbose=False)
+        assert n == 1 and bad == want, (lines, bad, want)
+
+
+def test_optional_workspace_allocation_failure_falls_back():
+    """the record workspace of the square-root small-block path's two-kernel backward pass is optional
+    (include/rodeo_kalman.h) -- if its allocation fails, SolvePlan leaves workspace = NULL and the library runs the one-kernel
+    form; a REQUIRED workspace (dense path) still raises.  No GPU: the plan is put together by hand around a fake device."""
+    import ctypes as C
+    import numpy as np
+    from rodeo_amd import _lib
+    from rodeo_amd.solve import SolvePlan
+    lib = _lib.load()
+
+    class FakeArr:
+        def __init__(self, shape, pad_bytes=0):
+            self.shape, self.nbytes, self.ptr = tuple(shape), int(np.prod(shape)) * 8 + pad_bytes, C.c_void_p(0x1000)
+
+    class FakeDev:
+        def __init__(self):
+            self.lib, self.h, self.refused = lib, None, []
+
+        def empty(self, shape, pad_bytes=0):
+            if len(shape) == 1:                                    # the workspace: a flat array of doubles
+                self.refused.append(shape[0])
+                raise MemoryError("simulated hipErrorOutOfMemory")
+            return FakeArr(shape, pad_bytes)
+
+    def plan_for(kalman, n_bstate, n_bmeas, n_block, rhs):
+        p = SolvePlan.__new__(SolvePlan)
+        p.dev, p.N, p.d, p.p, p.B = FakeDev(), 50, n_block, n_bstate, 8
+        p.cfg = _lib.SolveCfg(n_traj=8, n_steps=50, n_block=n_block, n_bstate=n_bstate, n_bmeas=n_bmeas, rhs_id=rhs,
+                              interrogate=_lib.INTERROGATE_KRAMER, kalman_type=kalman, n_theta=3, flags=0, t_min=0.0,
+                              t_max=1.0, seed=0, traj_offset=0)
+        p._store_pred, p._bufs, p._ws, p.layout = False, {}, None, None
+        p.mean_state = p.var_state = p.mean_pred = p.var_pred = p.x_state = None
+        return p
+
+    p = plan_for(_lib.KALMAN_SQRT, 3, 1, 2, _lib.RHS_FITZHUGH_NAGUMO)
+    p._prepare_out(_lib.MODE_MV)
+    assert p.dev.refused and p._ws is None and not p._out.workspace and p._out.workspace_bytes == 0
+    d = plan_for(_lib.KALMAN_STANDARD, 40, 8, 1, _lib.RHS_LINEAR_DENSE)          # the dense path NEEDS its workspace
+    with pytest.raises(MemoryError):
+        d._prepare_out(_lib.MODE_MV)
