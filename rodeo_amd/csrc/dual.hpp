@@ -184,23 +184,41 @@ struct AutoJac {
     // What the MFMA-tile kernels need (NDEP == 1, every lane works for ONE block): f_blk and d f_blk / d X[blk][0] from a
     // single evaluation with one dual direction, instead of D evaluations with P directions each.
     static constexpr bool HAS_FJAC0 = true;
+    template <class V, class = void> struct has_one_ { static constexpr bool value = false; };
+    template <class V> struct has_one_<V, decltype((void)V::HAS_RHS_ONE)> { static constexpr bool value = V::HAS_RHS_ONE; };
+    // a right-hand side with `rhs_one` (rodeo_amd.trace writes it): the lane's OWN block's output alone -- the full evaluation
+    // computes all D outputs in every lane and throws D - 1 of them away (a traced ring of 32 variables: 176 us per forward step)
+    static constexpr bool HAS_F_BLOCK = has_one_<U>::value;
     template <int P>
     __device__ __forceinline__ static void fjac0_block(const double (&X)[D][P], double t, const double (&th)[NTHETA],
                                                        int blk, double& fb, double& J0) {
-        Dual<1> Xd[D][P], od[D];
+        Dual<1> Xd[D][P];
 #pragma unroll
         for (int bb = 0; bb < D; ++bb) {
 #pragma unroll
             for (int j = 0; j < P; ++j) Xd[bb][j] = Dual<1>(X[bb][j]);
             Xd[bb][0].d[0] = bb == blk ? 1.0 : 0.0;
         }
-        U::template rhs<Dual<1>, P>(Xd, t, th, od);
-        fb = od[0].v; J0 = od[0].d[0];
+        if constexpr (has_one_<U>::value) {
+            Dual<1> o1;
+            U::template rhs_one<Dual<1>, P>(blk, Xd, t, th, o1);
+            fb = o1.v; J0 = o1.d[0];
+        } else {
+            Dual<1> od[D];
+            U::template rhs<Dual<1>, P>(Xd, t, th, od);
+            fb = od[0].v; J0 = od[0].d[0];
 #pragma unroll
-        for (int bb = 1; bb < D; ++bb) {
-            fb = bb == blk ? od[bb].v : fb;
-            J0 = bb == blk ? od[bb].d[0] : J0;
+            for (int bb = 1; bb < D; ++bb) {
+                fb = bb == blk ? od[bb].v : fb;
+                J0 = bb == blk ? od[bb].d[0] : J0;
+            }
         }
+    }
+    template <int P>
+    __device__ __forceinline__ static double f_block(const double (&X)[D][P], double t, const double (&th)[NTHETA], int blk) {
+        double o1 = 0.0;
+        if constexpr (has_one_<U>::value) U::template rhs_one<double, P>(blk, X, t, th, o1);
+        return o1;
     }
 };
 

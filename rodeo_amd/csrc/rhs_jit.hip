@@ -162,6 +162,13 @@ static int jit_get(rk_handle h, int rhs_id, int P, int itg, int kind, hipFunctio
         JitEntry e;
         RK_HIP(hipModuleLoadData(&e.mod, c.code.data()));
         RK_HIP(hipModuleGetFunction(&e.fn, e.mod, c.lowered.c_str()));
+        if (getenv("RK_JIT_VERBOSE")) {                   // resources of the kernel hiprtc built (a spilled dual copy of a big system shows here)
+            int regs = 0, scratch = 0, lds = 0;
+            (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, e.fn);
+            (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, e.fn);
+            (void)hipFuncGetAttribute(&lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, e.fn);
+            fprintf(stderr, "[rk] jit kernel %s: %d registers, %d B scratch per lane, %d B LDS\n", c.lowered.c_str(), regs, scratch, lds);
+        }
         it = g_cache.emplace(key, e).first;
     }
     *fn = it->second.fn;
@@ -177,7 +184,7 @@ bool user_tile_available(const rk_solve_cfg* c, int which) {
     if (idx < 0 || idx >= (int)g_rhs.size()) return false;
     const int nb = g_rhs[idx].n_block;
     if (c->n_block != nb || c->n_bmeas != 1 || g_rhs[idx].n_bmeas != 1 || c->kalman_type != RK_KALMAN_STANDARD) return false;
-    if (nb < 1 || nb > (which == 4 ? 4 : 16)) return false;      // p = 3 and blocked tiles: up to 16 blocks (4 per wave, LDS exchange); p = 4: one wave
+    if (nb < 1 || nb > (which == 4 ? 4 : 64)) return false;      // p = 3 and blocked tiles: up to 64 blocks (4 per wave, LDS exchange); p = 4: one wave
     // which = 5: the blocked tile kernel (solve_tilen_kernels.hpp), instantiated per NB = 1 (p = 4) / 2 (p = 5 .. 8)
     const int pkey = which == 5 ? (c->n_bstate <= 4 ? 1 : 2) : which;
     const JitCode& jc = jit_code_locked(c->rhs_id, pkey, c->interrogate, which);
@@ -304,7 +311,7 @@ int rk_register_rhs_source_m(const char* type_name, const char* source, int32_t 
                              int32_t* rhs_id) {
     RK_REQUIRE(type_name && source && rhs_id, RK_ERR_INVALID, "rk_register_rhs_source: null argument");
     // (n_bmeas > 4: one block holding all variables, served by the dense path -- solve_dense.hip)
-    RK_REQUIRE(n_block >= 1 && n_block <= 16 && n_theta >= 0 && n_bmeas >= 1 && (n_bmeas <= 4 || (n_block == 1 && n_bmeas <= 256)),
+    RK_REQUIRE(n_block >= 1 && n_block <= 64 && n_theta >= 0 && n_bmeas >= 1 && (n_bmeas <= 4 || (n_block == 1 && n_bmeas <= 256)),
                RK_ERR_INVALID, "rk_register_rhs_source: bad n_block / n_bmeas / n_theta");
     std::lock_guard<std::mutex> lk(g_mu);
     g_rhs.push_back(UserRhs{type_name, source, n_block, n_theta, n_bmeas});

@@ -33,10 +33,12 @@ __device__ __forceinline__ TileCoord tile_coord(int wave, int lane, int n_tiles)
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
-// n_block <= 4: one wave per workgroup carries whole trajectories (Tpw<D> tiles).  n_block = 5..16: a workgroup of
-// ceil(D / 4) waves is ONE trajectory, wave w holds blocks 4 w .. 4 w + 3, and the evaluation points of all blocks are
-// exchanged through LDS once per step (one barrier; double-buffered so that no second one is needed).
-constexpr int TILE_MAX_BLOCKS = 16;
+// n_block <= 4: one wave per workgroup carries whole trajectories (Tpw<D> tiles).  n_block = 5..64: a workgroup of
+// ceil(D / 4) waves (up to 16 = 1024 threads) is ONE trajectory, wave w holds blocks 4 w .. 4 w + 3, and the evaluation
+// points of all blocks are exchanged through LDS once per step (one barrier; double-buffered so that no second one is
+// needed).  The reference's block solver has no limit on n_block (src/rodeo/solve.py:47-68 vmaps over it); 64 is the
+// largest workgroup (round 3 stopped at 16: a 32-variable ODE could only run in the O((d p)^3) non-block form).
+constexpr int TILE_MAX_BLOCKS = 64;
 
 template <int D>
 struct TileWaves {                               // waves per forward workgroup
@@ -56,7 +58,7 @@ __device__ __forceinline__ double sqrt_pos_1step(double x) {
 template <class RHS, int ITG>
 __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kernel(SolveArgs a, double* __restrict__ tiles) {
     constexpr int D = RHS::D, P = 3, NW = TileWaves<D>::value, TPW = NW > 1 ? 4 : Tpw<D>::value;
-    static_assert(D >= 1 && D <= TILE_MAX_BLOCKS, "tile path: n_block in 1..16");
+    static_assert(D >= 1 && D <= TILE_MAX_BLOCKS, "tile path: n_block in 1..64");
     static_assert(RHS::NDEP == 1, "tile path: right-hand sides that depend on X[b][0] only");
     const int n_tiles = a.B * D;
     const int wave_in_wg = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -291,11 +293,10 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             const double a_meas = fma(l4, p2 * p1, fma(l3, p1 * n1, fma(l2, p1, fma(l1, n1, l0 * v_own))));
             Xw = fma(a_meas, e3r, XwL);
         } else {
-            double X[D][P];
-#pragma unroll
-            for (int bb = 0; bb < D; ++bb)
-#pragma unroll
-                for (int j = 0; j < P; ++j) X[bb][j] = 0.0;
+            // (one column: the tile path takes right-hand sides that read X[b][0] only, NDEP = 1 -- with all P columns the dual
+            //  copy of a 32-block system is 3 KB per lane and went to scratch: 45 us per forward step, round 4)
+            constexpr int PX = 1;
+            double X[D][PX];
             if constexpr (NW == 1) {
                 double vals[D];
                 gather_blocks<D>(v_own, vals);
@@ -309,17 +310,20 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
             }
             double fb, J0;
             if constexpr (ITG == RK_INTERROGATE_KRAMER && rhs_has_fjac0<RHS>::value) {
-                RHS::template fjac0_block<P>(X, t, th, blk, fb, J0);    // one evaluation, one dual direction (dual.hpp)
+                RHS::template fjac0_block<PX>(X, t, th, blk, fb, J0);    // one evaluation, one dual direction (dual.hpp)
+            } else if constexpr (ITG != RK_INTERROGATE_KRAMER && rhs_has_f_block<RHS>::value) {
+                fb = RHS::template f_block<PX>(X, t, th, blk);           // this lane's block alone
+                J0 = 0.0;
             } else {
-                double f[D], J[D][P];
+                double f[D], J[D][PX];
                 if constexpr (ITG == RK_INTERROGATE_KRAMER) {
-                    RHS::template fjac<P>(X, t, th, f, J);
+                    RHS::template fjac<PX>(X, t, th, f, J);
                 } else {
-                    RHS::template f<P>(X, t, th, f);
+                    RHS::template f<PX>(X, t, th, f);
 #pragma unroll
                     for (int bb = 0; bb < D; ++bb)
 #pragma unroll
-                        for (int j = 0; j < P; ++j) J[bb][j] = 0.0;
+                        for (int j = 0; j < PX; ++j) J[bb][j] = 0.0;
                 }
                 double J0s[D];
 #pragma unroll

@@ -77,7 +77,7 @@ __device__ __forceinline__ double bdot(const double (&u)[NB], const double (&v)[
 template <class RHS, int ITG, int NB>
 __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kernel(SolveArgs a, double* __restrict__ tiles, int P) {
     constexpr int D = RHS::D, NW = TileWaves<D>::value, TPW = NW > 1 ? 4 : Tpw<D>::value;
-    static_assert(D >= 1 && D <= TILE_MAX_BLOCKS, "tile path: n_block in 1..16");
+    static_assert(D >= 1 && D <= TILE_MAX_BLOCKS, "tile path: n_block in 1..64");
     static_assert(RHS::NDEP == 1, "tile path: right-hand sides that depend on X[b][0] only");
     const int n_units = a.B * D, PP = P * P + P;
     const int wave_in_wg = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -223,6 +223,9 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tilen_kerne
         }
         if constexpr (ITG == RK_INTERROGATE_KRAMER && rhs_has_fjac0<RHS>::value) {
             RHS::template fjac0_block<1>(X, t, th, blk, fb, J0);
+        } else if constexpr (ITG != RK_INTERROGATE_KRAMER && rhs_has_f_block<RHS>::value) {
+            fb = RHS::template f_block<1>(X, t, th, blk);       // this lane's block alone
+            J0 = 0.0;
         } else {
             double f[D], J[D][1];
             if constexpr (ITG == RK_INTERROGATE_KRAMER) {

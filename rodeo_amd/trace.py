@@ -132,11 +132,24 @@ def trace_source(fun, n_vars, n_deriv_used, param_spec, struct_name):
         for i in range(n_bmeas):
             lines.append(f"        out[{b}]{'[%d]' % i if n_bmeas > 1 else ''} = {Sym._c(out[b, i])};")
     body = "\n".join(lines)
+    # the same expressions one block at a time: on the tile kernels a lane needs the output of ITS block only, and evaluating
+    # all n_vars of them in every lane made a 32-variable ring's forward step 20 x slower than its arithmetic (round 4)
+    one = "\n".join(f"            case {b}: out = {Sym._c(out[b, 0])}; break;" for b in range(n_vars)) if n_bmeas == 1 else ""
     used = [j for b in range(n_vars) for j in range(n_deriv_used) if f"X[{b}][{j}]" in body]
     ndep = max(used) + 1 if used else 1
     n_theta = max(off, 0)
     out_t = "T (&out)[D][M]" if n_bmeas > 1 else "T (&out)[D]"
     m_line = f"\n    static constexpr int M = {n_bmeas};" if n_bmeas > 1 else ""
+    one_fn = f"""
+    static constexpr bool HAS_RHS_ONE = true;
+    // output b alone (b may differ from lane to lane: the wave runs the cases its lanes ask for)
+    template <class T, int P>
+    __device__ __forceinline__ static void rhs_one(int b, const T (&X)[D][P], double t, const double (&th)[NTHETA], T& out) {{
+        switch (b) {{
+{one}
+            default: break;
+        }}
+    }}""" if one else ""
     src = f"""
 // generated by rodeo_amd.trace from the Python function {getattr(fun, '__name__', 'ode_fun')!r}
 struct {struct_name} {{
@@ -147,7 +160,7 @@ struct {struct_name} {{
     __device__ __forceinline__ static void rhs(const T (&X)[D][P], double t, const double (&th)[NTHETA], {out_t}) {{
         static_assert(P >= NDEP, "the right-hand side reads more derivatives than the prior carries");
 {body}
-    }}
+    }}{one_fn}
 }};
 """
     return src, ndep, n_bmeas
