@@ -39,16 +39,62 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
     return ((double)x + 0.5) * (1.0 / 9007199254740992.0);
 }
 
+// log(u) for u in (0, 1) -- the uniform of Box-Muller -- in ~35 instructions where the library's log() takes about twice
+// that: frexp, m in [sqrt(1/2), sqrt 2), s = f / (2 + f) with the reciprocal of linalg_small.hpp, fdlibm's degree-7 polynomial
+// in s^2 (e_log.c: |error| < 2^-58 on that interval) and e ln 2 added by one FMA.  Absolute error ~1e-16 (1 + |log u|): the
+// draws are compared with the NumPy mirror (oracle/counter_rng.py) at 1e-7 and below along whole sample paths.
+__device__ __forceinline__ double bm_log01(double u) {
+    int e = __builtin_amdgcn_frexp_exp(u);                          // u = m 2^e, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(u);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double rr = __builtin_amdgcn_rcp(2.0 + f);
+    const double d = 2.0 + f;
+    double r2 = fma(fma(-d, rr, 1.0), rr, rr);
+    r2 = fma(fma(-d, r2, 1.0), r2, r2);
+    const double sv = f * r2;
+    const double z = sv * sv, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double hfsq = 0.5 * f * f;
+    const double lm = f - (hfsq - sv * (hfsq + (t1 + t2)));
+    return fma((double)e, 0.69314718055994530942, lm);
+}
+// sin(pi x), cos(pi x) for x in [0, 2]: quarter-turn reduction (exact: x - q / 2 is a difference of doubles with a common
+// exponent range), fdlibm's kernel polynomials on |a| <= pi / 4 (k_sin.c, k_cos.c: < 2^-58), the quadrant by selects.
+__device__ __forceinline__ void bm_sincospi02(double x, double& sn, double& cs) {
+    const double qd = __builtin_rint(x + x);                        // 0 .. 4
+    const double a = fma(qd, -0.5, x) * 3.14159265358979323846;
+    const int q = (int)qd;
+    const double z = a * a;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                   2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                    8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double s0 = fma(a * z, ps, a);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                   -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                    -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double c0 = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const bool sw = (q & 1) != 0;                                   // odd quarter turns swap sine and cosine
+    const double s1 = sw ? c0 : s0, c1 = sw ? s0 : c0;
+    sn = ((q + 0) & 2) ? -s1 : s1;                                  // q = 2, 3: sin < 0
+    cs = ((q + 1) & 2) ? -c1 : c1;                                  // q = 1, 2: cos < 0
+}
+
 // two standard normals for one counter
 __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t traj, uint32_t step, uint32_t block,
                                             uint32_t purpose, uint32_t chunk, double& z0, double& z1) {
     uint32_t r[4];
     philox4x32_10(traj, step, block | (purpose << 16), chunk, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     const double u1 = u53(r[0], r[1]), u2 = u53(r[2], r[3]);
-    // sqrt without the scaling branches of sqrt() (the argument is in [1.1e-16, 74]); sin / cos of 2 pi u2 through
-    // sincospi: exact range reduction instead of the generic large-argument path of sincos() -- together about half
-    // the instructions; the results differ from the NumPy mirror's cos(fl(2 pi u2)) by the rounding of the angle (1e-16)
-    const double t = -2.0 * log(u1);
+    // Box-Muller with its own log and sincospi (round 4: the generator was 72 of the 446 cycles of C4's forward step and most
+    // of its backward sampler's producer work; the library's log + sincospi are about twice the instructions of these two,
+    // which need neither special cases nor large arguments); sqrt without the scaling branches of sqrt() (the argument is in
+    // [1.1e-16, 74]).  The results differ from the NumPy mirror's at the 1e-15 level.
+    const double t = -2.0 * bm_log01(u1);
     const double rs = __builtin_amdgcn_rsq(t);
     double g = t * rs, h = 0.5 * rs;
     const double e = fma(-h, g, 0.5);
@@ -56,7 +102,7 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t traj, uint32
     h = fma(h, e, h);
     const double rad = fma(fma(-g, g, t), h, g);
     double s, c;
-    sincospi(2.0 * u2, &s, &c);
+    bm_sincospi02(2.0 * u2, s, c);
     z0 = rad * c;
     z1 = rad * s;
 }
