@@ -321,7 +321,9 @@ int rk_kalman_smooth_cond_batched(rk_handle h, const rk_op_cfg* c,
  * One interrogation for a batch of predicted states: src/rodeo/interrogate.py (all four variants; the variant,
  * rhs, dims, seed and traj_offset are taken from cfg; `step` addresses the Philox stream for chkrebtii).
  *   mean_state_pred (d, p, B), var_state_pred (d, p, p, B), ode_weight/theta as in rk_solve_in;
- *   outputs wgt_meas (d, m, p, B), mean_meas (d, m, B), var_meas (d, m, m, B).                               */
+ *   outputs wgt_meas (d, m, p, B), mean_meas (d, m, B), var_meas (d, m, m, B); any n_bmeas m for a registered
+ *   right-hand side.  cfg->kalman_type = RK_KALMAN_SQRT matters to chkrebtii only (interrogate.py:35-42, m = 1):
+ *   var_state_pred is then the factor L-, var_meas = W L- has shape (d, 1, p, B) and the draw is mu- + (W L-) z.  */
 int rk_interrogate_batched(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, double t, int32_t step,
         const double* mean_state_pred, const double* var_state_pred,
         double* wgt_meas, double* mean_meas, double* var_meas);

@@ -74,6 +74,7 @@ static std::string kernel_expr(const UserRhs& u, int P, int itg, int kind) {
     char buf[512];
     (void)u;   // the user's type is aliased to rk::UserRhsT inside the translation unit (it may be a template-id)
     if (kind == 2) snprintf(buf, sizeof buf, "rk::interrogate_kernel<rk::UserRhsT, %d, %d>", P, itg);
+    else if (kind == 10) snprintf(buf, sizeof buf, "rk::interrogate_kernel_m<rk::UserRhsT, %d, %d>", P, itg);      // n_bmeas > 1, standalone
     else if (kind == 3) snprintf(buf, sizeof buf, "rk::fwd_tile3_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 3
     else if (kind == 4) snprintf(buf, sizeof buf, "rk::fwd_tile4_kernel<rk::UserRhsT, %d>", itg);      // MFMA-tile forward, p = 4
     else if (kind == 7 || kind == 8)                                                                        // n_bmeas > 1
@@ -291,12 +292,15 @@ int user_interrogate(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, dou
                      const double* vp, double* wm, double* mm_, double* vm) {
     int rc = user_rhs_check(c);
     if (rc) return rc;
-    RK_REQUIRE(c->n_bmeas == 1, RK_ERR_UNSUPPORTED, "rk_interrogate_batched: n_bmeas = 1 only (n_bmeas > 1 runs fused in the solvers)");
+    const bool multi = c->n_bmeas > 1;                     // several measurements per block: interrogate_kernel_m
+    RK_REQUIRE(!multi || c->kalman_type == RK_KALMAN_STANDARD, RK_ERR_UNSUPPORTED,
+               "rk_interrogate_batched: n_bmeas > 1 with kalman_type = square-root is fused into the solvers only");
     hipFunction_t fn;
-    rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, 2, &fn);
+    rc = jit_get(h, c->rhs_id, c->n_bstate, c->interrogate, multi ? 10 : 2, &fn);
     if (rc) return rc;
     SolveArgs args = a;
-    void* params[] = {&args, &t, &step, &mp, &vp, &wm, &mm_, &vm};
+    int sqrt_mode = c->kalman_type == RK_KALMAN_SQRT ? 1 : 0;
+    void* params[] = {&args, &t, &step, &mp, &vp, &wm, &mm_, &vm, &sqrt_mode};
     RK_HIP(hipModuleLaunchKernel(fn, div_up(a.B, 64), 1, 1, 64, 1, 1, 0, h->stream, params, nullptr));
     return RK_OK;
 }
@@ -334,7 +338,9 @@ int rk_rhs_compile_check(int32_t rhs_id, int32_t n_bstate, int32_t interrogate) 
     std::vector<char> code;
     std::string lowered;
     const bool dense = u.n_block == 1 && u.n_bmeas > 1 && (n_bstate > 9 || u.n_bmeas > 4);      // (user_dense_wanted)
-    return jit_compile(u, n_bstate, interrogate, dense ? 9 : (u.n_bmeas > 1 ? 7 : 0), code, lowered);
+    int rc = jit_compile(u, n_bstate, interrogate, dense ? 9 : (u.n_bmeas > 1 ? 7 : 0), code, lowered);
+    if (rc == RK_OK && !dense && u.n_bmeas > 1) rc = jit_compile(u, n_bstate, interrogate, 10, code, lowered);     // + the standalone interrogation
+    return rc;
 }
 
 }  // extern "C"

@@ -535,8 +535,9 @@ static int launch_itg_rhs(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a
     RK_REQUIRE(c->n_block == RHS::D && c->n_bmeas == 1, RK_ERR_UNSUPPORTED,
                "rhs %d needs n_block=%d, n_bmeas=1 (got %d, %d)", c->rhs_id, RHS::D, c->n_block, c->n_bmeas);
     const dim3 grid(div_up(a.B, 64)), block(64);
+    const int sqrt_mode = c->kalman_type == RK_KALMAN_SQRT ? 1 : 0;      // only interrogate_chkrebtii reads it
 #define RK_ITG2(P_, I_)                                                                                          \
-    hipLaunchKernelGGL((interrogate_kernel<RHS, P_, I_>), grid, block, 0, h->stream, a, t, step, mp, vp, wm, mm_, vm)
+    hipLaunchKernelGGL((interrogate_kernel<RHS, P_, I_>), grid, block, 0, h->stream, a, t, step, mp, vp, wm, mm_, vm, sqrt_mode)
 #define RK_ITG(P_)                                                                      \
     case P_:                                                                            \
         switch (c->interrogate) {                                                       \

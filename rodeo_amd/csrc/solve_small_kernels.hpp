@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(64) fwd_kernel(SolveArgs a) {
 template <class RHS, int P, int ITG>
 __global__ void __launch_bounds__(64) interrogate_kernel(SolveArgs a, double t, int step, const double* mean_pred,
                                                          const double* var_pred, double* wgt_meas,
-                                                         double* mean_meas, double* var_meas) {
+                                                         double* mean_meas, double* var_meas, int sqrt_mode) {
     constexpr int D = RHS::D;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
@@ -177,6 +177,36 @@ __global__ void __launch_bounds__(64) interrogate_kernel(SolveArgs a, double t, 
     for (int k = 0; k < RHS::NTHETA; ++k) th[k] = a.theta ? ld(a.theta, k, a.theta_b, a.B, b) : 0.0;
     double wgt[D][P], am[D], V[D];
     const uint32_t traj = (uint32_t)(a.traj_offset + (uint64_t)b);
+    if constexpr (ITG == RK_INTERROGATE_CHKREBTII) {
+        if (sqrt_mode) {
+            // interrogate.py:35-42 (kalman_type = "square-root"): var_state_pred is the FACTOR L-, var_meas = W L- has shape
+            // (1, p) and the draw is mu- + (W L-) . z, one scalar added to every entry; the factor's column signs are
+            // normalised (diag >= 0) like in the fused kernels and the oracle.  var_meas here: (d, 1, p, B).
+            double xs[D][P], f[D];
+#pragma unroll
+            for (int blk = 0; blk < D; ++blk) {
+                double z[P], WL[P];
+                normals<P>(a.seed, traj, (uint32_t)step, (uint32_t)blk, PURPOSE_INTERROGATE, z);
+                double shift = 0.0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    double sj = W[blk][0] * Sp[blk][0][j];
+#pragma unroll
+                    for (int i = 1; i < P; ++i) sj = fma(W[blk][i], Sp[blk][i][j], sj);
+                    WL[j] = sj;
+                    shift = fma(sj, Sp[blk][j][j] < 0.0 ? -z[j] : z[j], shift);
+                    var_meas[((size_t)blk * P + j) * B + b] = sj;
+                    wgt_meas[((size_t)blk * P + j) * B + b] = 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < P; ++j) xs[blk][j] = mup[blk][j] + shift;
+            }
+            RHS::template f<P>(xs, t, th, f);
+#pragma unroll
+            for (int blk = 0; blk < D; ++blk) mean_meas[(size_t)blk * B + b] = -f[blk];
+            return;
+        }
+    }
     interrogate_traj<RHS, P, ITG>(W, th, t, mup, Sp, a.seed, traj, (uint32_t)step, wgt, am, V);
 #pragma unroll
     for (int blk = 0; blk < D; ++blk) {

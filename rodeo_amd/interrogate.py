@@ -19,7 +19,7 @@ from .device import default_device, batch_minor
 from .ode import DeviceODE
 
 
-def _run(itg_id, key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, params):
+def _run(itg_id, key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, params, sqrt=False):
     if not isinstance(ode_fun, DeviceODE):
         raise TypeError("ode_fun must be a rodeo_amd.ode.DeviceODE (device code for the right-hand side)")
     dev = default_device()
@@ -27,8 +27,9 @@ def _run(itg_id, key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, p
     mp = np.asarray(mean_state_pred, dtype=np.float64)
     vp = np.asarray(var_state_pred, dtype=np.float64)
     d, m, p = W.shape[-3:]
-    if m != 1:
-        raise NotImplementedError("rk_interrogate_batched: n_bmeas = 1 only (small-block path)")
+    if m != 1 and sqrt:
+        raise NotImplementedError("standalone interrogate_chkrebtii(kalman_type='square-root') with n_bmeas > 1 is only "
+                                  "available fused into solve_mv / solve_sim")
     theta, Bt = ode_fun.pack_params(params)
     batched = mp.ndim == 3 or vp.ndim == 4 or Bt is not None or W.ndim == 4
     B = next(s for s in ([mp.shape[0]] if mp.ndim == 3 else []) + ([vp.shape[0]] if vp.ndim == 4 else []) +
@@ -43,7 +44,7 @@ def _run(itg_id, key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, p
         else:
             seed = int(key)
     cfg = _lib.SolveCfg(n_traj=B, n_steps=1, n_block=d, n_bstate=p, n_bmeas=m, rhs_id=ode_fun.rhs_id,
-                        interrogate=itg_id, kalman_type=_lib.KALMAN_STANDARD, n_theta=ode_fun.n_theta, flags=0,
+                        interrogate=itg_id, kalman_type=_lib.KALMAN_SQRT if sqrt else _lib.KALMAN_STANDARD, n_theta=ode_fun.n_theta, flags=0,
                         t_min=0.0, t_max=1.0, seed=seed & 0xFFFFFFFFFFFFFFFF, traj_offset=off)
     dW = dev.to_device(batch_minor(W, W.ndim == 4))
     dth = dev.to_device(batch_minor(theta, Bt is not None)) if theta.size else None
@@ -51,7 +52,7 @@ def _run(itg_id, key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, p
                        prior_weight=None, prior_weight_batched=0, prior_var=None, prior_var_batched=0,
                        theta=dth.ptr if dth is not None else None, theta_batched=int(Bt is not None))
     dmp, dvp = dev.to_device(batch_minor(mp, True)), dev.to_device(batch_minor(vp, True))
-    wm, mm, vm = dev.empty((d, m, p, B)), dev.empty((d, m, B)), dev.empty((d, m, m, B))
+    wm, mm, vm = dev.empty((d, m, p, B)), dev.empty((d, m, B)), dev.empty((d, m, p if sqrt else m, B))
     _lib.check(dev.lib.rk_interrogate_batched(dev.h, C.byref(cfg), C.byref(inp), float(t), int(step),
                                               dmp.ptr, dvp.ptr, wm.ptr, mm.ptr, vm.ptr))
     out = wm.batch_first(), mm.batch_first(), vm.batch_first()
@@ -74,10 +75,10 @@ def interrogate_kramer(key, ode_fun, ode_weight, t, mean_state_pred, var_state_p
 
 
 def interrogate_chkrebtii(key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, kalman_type, **params):
-    """src/rodeo/interrogate.py:13-47: x ~ N(mu-, Sigma-), mean_meas = -f(x), var_meas = W Sigma- W^T."""
-    if kalman_type == "square-root":
-        raise NotImplementedError("standalone interrogate_chkrebtii(kalman_type='square-root') is only available fused "
-                                  "into solve_mv / solve_sim")
-    if kalman_type != "standard":
+    """src/rodeo/interrogate.py:13-47: "standard": x ~ N(mu-, Sigma-), mean_meas = -f(x), var_meas = W Sigma- W^T.
+    "square-root" (interrogate.py:35-42): var_state_pred is the factor L-, var_meas = W L- of shape (d, m, p) and
+    x = mu- + (W L-) z (one scalar per block added to every entry, as the reference's broadcast does); n_bmeas = 1."""
+    if kalman_type not in ("standard", "square-root"):
         raise NotImplementedError                       # src/rodeo/interrogate.py:43-44
-    return _run(_lib.INTERROGATE_CHKREBTII, key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, params)
+    return _run(_lib.INTERROGATE_CHKREBTII, key, ode_fun, ode_weight, t, mean_state_pred, var_state_pred, params,
+                sqrt=kalman_type == "square-root")

@@ -545,3 +545,69 @@ def test_several_measurements_per_block_non_block_form(ra):
         m, v = ra.solve_mv(None, two, W2, x2, 0.0, N2 / 30.0, N2, g, pr2, k=k)
         mo, vo = scan.solve_mv(None, o2, W2, x2, 0.0, N2 / 30.0, N2, o, pr2, k=k)
         assert np.max(np.abs(m - mo)) < 1e-8 * max(1.0, np.max(np.abs(mo))) and np.max(np.abs(v - vo)) < 1e-7 * np.max(np.abs(vo))
+
+
+def test_standalone_interrogations_with_several_measurements_per_block(ra):
+    """The four interrogate_* called directly (src/rodeo/interrogate.py:13-115) for an ode_fun returning
+    (n_block, n_bmeas = 2): wgt_meas (d, 2, p), mean_meas (d, 2), var_meas (d, 2, 2) against the oracle, batched
+    predicted moments and parameters; chkrebtii addressed at (seed, step, traj_offset) like the fused solver."""
+    def two(X, t, k):
+        return np.array([[-k[0] * X[0, 0] + X[1, 2], np.sin(X[0, 0]) - X[0, 2]],
+                         [-k[1] * X[1, 0] * X[0, 2], X[0, 0] - X[1, 2]]])
+
+    def host2(X, t, k):
+        kk = np.asarray(k, dtype=np.float64)
+        return np.stack([np.stack([-kk[..., 0] * X[..., 0, 0] + X[..., 1, 2], np.sin(X[..., 0, 0]) - X[..., 0, 2]], axis=-1),
+                         np.stack([-kk[..., 1] * X[..., 1, 0] * X[..., 0, 2], X[..., 0, 0] - X[..., 1, 2]], axis=-1)], axis=-2)
+    o2 = odes.ODE("two", 2, 2, host2, lambda X, t, k: odes.complex_step_blockjac(odes.ODE("t", 2, 2, host2, None), X, t, k=k))
+    dev_ode = ra.ode.from_python(two, 2, 4, k=2)
+    assert dev_ode.n_bmeas == 2
+    B, d, p = 70, 2, 4                                                      # two waves, the second ragged
+    rng = np.random.default_rng(5)
+    W = np.zeros((d, 2, p)); W[:, 0, 1] = 1.0; W[:, 1, 3] = 1.0
+    k = np.array([0.7, 1.3]) * np.exp(0.05 * rng.standard_normal((B, 2)))
+    mp = rng.standard_normal((B, d, p))
+    A = rng.standard_normal((B, d, p, p))
+    vp = A @ np.swapaxes(A, -1, -2) + 0.1 * np.eye(p)
+    for name in ("kramer", "rodeo", "schober", "chkrebtii"):
+        g, o = getattr(ra.interrogate, "interrogate_" + name), getattr(oi, "interrogate_" + name)
+        kw = dict(kalman_type="standard") if name == "chkrebtii" else {}
+        gkey = (9, 3, 100) if name == "chkrebtii" else None
+        okey = oi.StepKey(9, 100 + np.arange(B), 3) if name == "chkrebtii" else None
+        w1, m1, v1 = g(gkey, dev_ode, W, 0.4, mp, vp, k=k, **kw)
+        w0, m0, v0 = o(okey, o2, W, 0.4, mp, vp, k=k, **kw)
+        assert w1.shape == (B, d, 2, p) and m1.shape == (B, d, 2) and v1.shape == (B, d, 2, 2)
+        assert np.max(np.abs(w1 - np.broadcast_to(w0, w1.shape))) < 1e-9, name
+        assert np.max(np.abs(m1 - m0)) < 1e-9 * max(1.0, np.max(np.abs(m0))), name
+        assert np.max(np.abs(v1 - np.broadcast_to(v0, v1.shape))) < 1e-12 * max(1.0, np.max(np.abs(v0))), name
+    # unbatched call returns unbatched arrays
+    w1, m1, v1 = ra.interrogate.interrogate_rodeo(None, dev_ode, W, 0.4, mp[0], vp[0], k=k[0])
+    assert w1.shape == (d, 2, p) and m1.shape == (d, 2) and v1.shape == (d, 2, 2)
+
+
+def test_standalone_chkrebtii_square_root_form(ra):
+    """interrogate_chkrebtii(kalman_type="square-root") called directly (src/rodeo/interrogate.py:35-42): var_state_pred is
+    the factor, var_meas = W L- has shape (d, 1, p), the draw is mu- + (W L-) z with the factor's column signs normalised
+    (oracle/interrogations.py).  Built-in and traced right-hand sides, factors with negative diagonal entries."""
+    B, d, p = 70, 2, 3
+    rng = np.random.default_rng(6)
+    W, _ = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    theta = np.array([.2, .2, 3.]) * np.exp(0.1 * rng.standard_normal((B, 3)))
+    mp = rng.standard_normal((B, d, p))
+    L = np.tril(rng.standard_normal((B, d, p, p)))                         # diagonal of either sign
+    assert (np.einsum("...ii->...i", L) < 0).any()
+    okey = oi.StepKey(21, 7 + np.arange(B), 5)
+
+    def fitz(X, t, theta):
+        a, b, c = theta
+        V, R = X[0, 0], X[1, 0]
+        return np.array([[c * (V - V * V * V / 3 + R)], [-1 / c * (V - a + b * R)]])
+    for ode_fun in (ra.ode.fitzhugh_nagumo, ra.ode.from_python(fitz, 2, 1, theta=3)):
+        w1, m1, v1 = ra.interrogate.interrogate_chkrebtii((21, 5, 7), ode_fun, W, 0.4, mp, L, "square-root", theta=theta)
+        w0, m0, v0 = oi.interrogate_chkrebtii(okey, odes.fitzhugh_nagumo, W, 0.4, mp, L, kalman_type="square-root", theta=theta)
+        assert v1.shape == (B, d, 1, p) and m1.shape == (B, d, 1)
+        assert np.all(w1 == 0.0)
+        assert np.max(np.abs(v1 - v0)) < 1e-14 * max(1.0, np.max(np.abs(v0)))
+        assert np.max(np.abs(m1 - m0)) < 1e-10 * max(1.0, np.max(np.abs(m0)))
+    with pytest.raises(NotImplementedError):
+        ra.interrogate.interrogate_chkrebtii(1, ra.ode.fitzhugh_nagumo, W, 0.4, mp, L, "cholesky", theta=theta)
