@@ -1057,6 +1057,8 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
                 RK_WSTAMP(3, tw0_);
             } else {
                 // column tiles in the order: trailing tiles 1 .. ta - 1, right-hand-side tiles 0 .. tb - 1
+                // (round 4: leaving wave 4 idle -- it shares SIMD 0 with the panel wave -- did not shorten the panel chain, 369 k ->
+                //  382 k cycles, and stretched the strips, 399 k -> 421 k: the chain is not held up by its SIMD partner's MFMAs)
                 const int ta = nrt >> 4, tb = nbp >> 4, T = ta - 1 + tb, per = (T + NWAVE - 2) / (NWAVE - 1);
                 const int g0 = (wave - 1) * per, g1 = min(T, g0 + per);
                 if (g0 < g1) {
@@ -1309,57 +1311,97 @@ __device__ __noinline__ void wg_bd_right(double* C_, const double* X_, const dou
 template <int ND>
 __device__ __forceinline__ void wg_bd_predict_nd(gd* C, gd* C2, gd* D, cgd* X, cgd* E, cgd* F, int p) {
     const double* const qd = g_qd;
-    const int nblk = p / ND, total = nblk * nblk;
-    for (int e = threadIdx.x; e < total; e += DT) {
-        const int ib = e / nblk, jb = e - ib * nblk, i0 = ib * ND, j0 = jb * ND;
-        // (block, mirror block) -> (Q_I x, Q_I xm^T) first, the additive terms row by row afterwards: all six 5 x 5 blocks at
-        //  once are 300 registers (the first version spilled and ran slower than the two passes)
-        double y[ND][ND], yt[ND][ND];
-        {
-            double x[ND][ND], xm[ND][ND];
+    double* const stg = g_lds;
+    const int nblk = p / ND;
+    // Whole block rows per sweep, so that what a sweep produces is ONE contiguous range of rows of each output: the results go
+    // to LDS at their place in that range (one region per output) and leave as flat, fully coalesced copies, 16 bytes per lane.
+    // Stored straight from the block's thread -- 8-byte pieces 40 bytes apart, five instructions per cache line, every piece
+    // a 32-byte write request -- the three outputs cost 80 k of the pass's 212 k cycles at (160, 5) (stamps of round 4, DESIGN.md
+    // section 4).  Two kinds of thread per block when T^T is wanted: kind 0 takes block (I, J) to Sigma^- and D, kind 1 takes the
+    // mirror block (J, I) to T^T (one thread doing both holds 100 doubles of results and spills).  The loads stay per block:
+    // staging the bands of Sigma and F through LDS as well (flat copies in, the column band as [p][W]) was measured slower
+    // (181 k against 166 k cycles for the pass) -- a CU has ~48 KB of loads in flight either way.
+    const int nreg = 1 + (C2 ? 1 : 0) + (D ? 1 : 0), kinds = C2 ? 2 : 1;
+    const int rb = max(1, min((DT / kinds) / nblk, LDS_DOUBLES / (nreg * ND * p)));          // block rows per sweep
+    const int per = rb * nblk, reg = rb * ND * p;                          // blocks per sweep; doubles per LDS region
+    const int regD = reg, regT = D ? 2 * reg : reg;
+    const bool vst = (p & 1) == 0 && (reg & 1) == 0 && ((((size_t)C) | ((size_t)C2) | ((size_t)D)) & 15) == 0;
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    auto flush = [&](gd* O, int roff, int row0, int nrows) {               // LDS region -> rows row0 .. of O
+        const int n_el = nrows * p;
+        gd* const o = O + (size_t)row0 * p;
+        if (vst) {
+            for (int e = 2 * threadIdx.x; e < n_el; e += 2 * DT) {
+                d2v v; v.x = stg[roff + e]; v.y = stg[roff + e + 1];
+                *reinterpret_cast<__attribute__((address_space(1))) d2v*>(o + e) = v;
+            }
+        } else {
+            for (int e = threadIdx.x; e < n_el; e += DT) o[e] = stg[roff + e];
+        }
+    };
+    __syncthreads();                                                        // (the LDS buffer may still be read by the phase in front)
+    for (int ib0 = 0; ib0 < nblk; ib0 += rb) {
+        const int nbr = min(rb, nblk - ib0), W = nbr * ND;                  // block rows, rows of this sweep
+        const int t = threadIdx.x;
+        const int kind = t >= per ? 1 : 0, idx = t - kind * per;
+        const bool on = idx < nbr * nblk && kind < kinds;
+        const int ibl = on ? idx / nblk : 0, jb = on ? idx - ibl * nblk : 0, i0 = (ib0 + ibl) * ND, j0 = jb * ND;
+        const int lo_ = (ibl * ND) * p + j0;                               // the block's place in the sweep's row range
+        double x[ND][ND], fv[ND][ND];                                       // kind 0: block (I, J) of Sigma, of F; kind 1: the mirror block
+        if (on) {
 #pragma unroll
             for (int r = 0; r < ND; ++r)
 #pragma unroll
                 for (int c = 0; c < ND; ++c) {
-                    x[r][c] = X[(i0 + r) * p + j0 + c];
-                    if (C2) xm[r][c] = X[(j0 + r) * p + i0 + c];     // block (J, I): xm[r][c] = Sigma[j0 + r][i0 + c]
+                    x[r][c] = kind == 0 ? X[(i0 + r) * p + j0 + c] : X[(j0 + r) * p + i0 + c];
+                    if (D) fv[r][c] = kind == 0 ? F[(i0 + r) * p + j0 + c] : 0.0;
                 }
-            // y = Q_I x (k ascending, like wg_bd_left); yt = Q_I xm^T
+        }
+        if (on && kind == 0) {
+            double y[ND][ND];
+            // y = Q_I x (k ascending, like wg_bd_left)
 #pragma unroll
             for (int r = 0; r < ND; ++r)
 #pragma unroll
                 for (int c = 0; c < ND; ++c) {
-                    double s_ = 0.0, st = 0.0;
+                    double s_ = 0.0;
 #pragma unroll
-                    for (int k = 0; k < ND; ++k) {
-                        s_ = fma(qd[(i0 + r) * BD_MAX + k], x[k][c], s_);
-                        if (C2) st = fma(qd[(i0 + r) * BD_MAX + k], xm[c][k], st);
-                    }
+                    for (int k = 0; k < ND; ++k) s_ = fma(qd[(i0 + r) * BD_MAX + k], x[k][c], s_);
                     y[r][c] = s_;
-                    yt[r][c] = st;
+                }
+#pragma unroll
+            for (int r = 0; r < ND; ++r) {
+                double ev[ND];
+#pragma unroll
+                for (int c = 0; c < ND; ++c) ev[c] = E[(i0 + r) * p + j0 + c];
+#pragma unroll
+                for (int c = 0; c < ND; ++c) {
+                    double s_ = 0.0;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) s_ = fma(y[r][k], qd[(j0 + c) * BD_MAX + k], s_);     // (like wg_bd_right)
+                    const double cv = ev[c] + s_;
+                    stg[lo_ + r * p + c] = cv;
+                    if (D) stg[regD + lo_ + r * p + c] = fv[r][c] - cv;
+                }
+            }
+        } else if (on) {
+            // T^T block (I, J) = Q_I (Sigma_f block (J, I))^T: x[r][c] = Sigma[j0 + r][i0 + c]
+#pragma unroll
+            for (int r = 0; r < ND; ++r)
+#pragma unroll
+                for (int c = 0; c < ND; ++c) {
+                    double st = 0.0;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) st = fma(qd[(i0 + r) * BD_MAX + k], x[c][k], st);
+                    stg[regT + lo_ + r * p + c] = st;
                 }
         }
-#pragma unroll
-        for (int r = 0; r < ND; ++r) {
-            double ev[ND], fv[ND];
-#pragma unroll
-            for (int c = 0; c < ND; ++c) {
-                ev[c] = E[(i0 + r) * p + j0 + c];
-                if (D) fv[c] = F[(i0 + r) * p + j0 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < ND; ++c) {
-                double s_ = 0.0;
-#pragma unroll
-                for (int k = 0; k < ND; ++k) s_ = fma(y[r][k], qd[(j0 + c) * BD_MAX + k], s_);     // (like wg_bd_right)
-                const double cv = ev[c] + s_;
-                C[(i0 + r) * p + j0 + c] = cv;
-                if (C2) C2[(i0 + r) * p + j0 + c] = yt[r][c];
-                if (D) D[(i0 + r) * p + j0 + c] = fv[c] - cv;
-            }
-        }
+        __syncthreads();
+        flush(C, 0, ib0 * ND, W);
+        if (D) flush(D, regD, ib0 * ND, W);
+        if (C2) flush(C2, regT, ib0 * ND, W);
+        __syncthreads();
     }
-    __syncthreads();
 }
 // returns false if nd has no instance (the caller then runs the two passes)
 __device__ __noinline__ bool wg_bd_predict(double* C_, double* C2_, double* D_, const double* X_, const double* E_, const double* F_,
