@@ -11,6 +11,7 @@
 // = 160 B = the algorithmic p (p + 1) 8 bytes.  With n_block = 3 a wave carries the three blocks of ONE trajectory in
 // tiles g = 0..2 (g = 3 idles); with n_block = 2 two trajectories; with n_block = 1 four.
 #include <algorithm>
+#include <cstdlib>
 #include "common.hpp"
 #include "kalman_small.hpp"
 #include "mfma_tile.hpp"
@@ -46,9 +47,16 @@ __device__ __forceinline__ int lds4_vec(int s, int g, int which, int rr) {
 #else
 #define T4_STAMP_ARG
 #endif
-template <int D>
-__global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, double* __restrict__ tiles T4_STAMP_ARG) {
+// SETS = 1, NP = 3: the 4-wave workgroup described above, two of them on a CU.
+// SETS = 2, NP = 2 (round 4, "a SIMD of its own for the chain"): ONE 8-wave workgroup per CU carries two such sets.  The waves of a
+// workgroup go to the SIMDs in turn (wave w on SIMD w mod 4, HW_ID probe), so waves 0 and 1 -- the two consumers -- sit on
+// SIMD 0 and SIMD 1, waves 4 and 5 leave at once and keep those SIMDs free of anything else, and the producers are waves
+// 2, 6 (set 0, SIMD 2) and 3, 7 (set 1, SIMD 3): two per set, each taking every other chunk through stages 1 + 2 in one tick
+// and stage 3 in the next.
+template <int D, int NP, int SETS>
+__global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_kernel(SolveArgs a, double* __restrict__ tiles T4_STAMP_ARG) {
     constexpr int P = 4, P4 = 4, TPW = Tpw<D>::value;
+    static_assert((SETS == 1 && NP == 3) || (SETS == 2 && NP == 2), "wave roles are written for these two shapes");
     // time steps per hand-off: 16 with three tiles per wave, 12 with four -- 74 KiB of LDS either way, so that TWO
     // workgroups share a CU (with 16 steps x 4 tiles: 96 KiB, one workgroup per CU, the chain waves idle half the time)
     constexpr int CH4 = TPW == 3 ? 16 : 12;
@@ -56,19 +64,41 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
     constexpr int ROW_BYTES = TPW * T4_DOUBLES * 8;                // this tile-wave's bytes per time row: 480 / 640
     constexpr int N_DMA = (CH4 * ROW_BYTES / 16 + 63) / 64;        // 1-KiB LDS-DMA pieces per chunk: 8 / 10
     constexpr int ZONE = N_DMA * 1024;
-    __shared__ __attribute__((aligned(16))) char lds_all[2 * BUF];
-    __shared__ __attribute__((aligned(16))) char zones[3 * ZONE];
+    __shared__ __attribute__((aligned(16))) char lds_all_[SETS][2 * BUF];
+    __shared__ __attribute__((aligned(16))) char zones_[SETS][NP * ZONE];
     // Q | R of this workgroup's TPW blocks: 64 registers per producer lane if they were kept across ticks, which is
     // what pushed the kernel over 256 registers = one workgroup per CU (the stride keeps the four blocks' rows in
     // different banks; lanes of one block read the same address)
     constexpr int QR_STRIDE = 2 * P4 * P4 + 2;
-    __shared__ __attribute__((aligned(16))) double qr[4 * QR_STRIDE];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;    // 0 = consumer; producers q = wave - 1 own ch = q (mod 3)
+    __shared__ __attribute__((aligned(16))) double qr_[SETS][4 * QR_STRIDE];
+    const int hw_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // role: 0 = consumer; producers q = role - 1 own the chunks ch = q (mod NP)
+    const int set = SETS == 1 ? 0 : (hw_wave & 1);
+    const int wave = SETS == 1 ? hw_wave : (hw_wave < 2 ? 0 : (hw_wave < 4 ? 1 : (hw_wave < 6 ? -1 : 2)));
+#ifdef RK_T4_STAMPS
+    if (lane == 0) {                                               // where the dispatcher put each of the workgroup's waves: slot 19 of its first tile-wave
+        unsigned hw_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+        atomicOr((unsigned long long*)&dbg[(size_t)blockIdx.x * SETS * 20 + 19], (unsigned long long)(((hw_ >> 4) & 3) | 4) << (4 * hw_wave));
+    }
+#endif
+    if (wave < 0) return;                                          // (SETS = 2: waves 4, 5 only keep SIMD 0, 1 free)
+#if defined(RK_T4_EXP) && RK_T4_EXP == 1                      // experiment builds (results wrong by construction): the second set without its producers,
+    if (SETS == 2 && set == 1 && wave >= 1) return;
+#elif defined(RK_T4_EXP) && RK_T4_EXP == 2                    // ... without its consumer,
+    if (SETS == 2 && set == 1 && wave == 0) return;
+#elif defined(RK_T4_EXP) && RK_T4_EXP == 3                    // ... not at all (one set per 8-wave workgroup, the other half of the tile-waves unprocessed)
+    if (SETS == 2 && set == 1) return;
+#endif
+    char* const lds_all = lds_all_[set];
+    char* const zones = zones_[set];
+    double* const qr = qr_[set];
     const int n_tiles = a.B * D;
     const size_t tstride = (size_t)n_tiles * T4_DOUBLES;
     const size_t row_bytes = tstride * sizeof(double);
     const int n_chunks = (a.N - 1 + CH4 - 1) / CH4;                // steps n = N-1 .. 1
-    const int tw = blockIdx.x;                                     // tile-wave: tiles TPW tw .. TPW tw + TPW - 1
+    const int tw = blockIdx.x * SETS + set;                        // tile-wave: tiles TPW tw .. TPW tw + TPW - 1
+    if (SETS > 1 && tw * TPW >= n_tiles) return;                   // (an odd number of tile-waves: the whole second set leaves before any barrier)
     const char* const wave_rows = (const char*)(tiles + (size_t)tw * TPW * T4_DOUBLES);
 
     if (wave >= 1) {
@@ -121,13 +151,14 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
 #if RK_T4_STAMPS >= 2
         long long acc[4] = {0, 0, 0, 0};
 #endif
-        for (int t = -3; t < n_chunks; ++t) {
-            const int ch1 = t + 3, ch2 = t + 2, ch3 = t + 1;
+        for (int t = -NP; t < n_chunks; ++t) {
+            // NP = 3: one stage per tick (chunk t + 3, t + 2 or t + 1); NP = 2: stages 1 and 2 of chunk t + 2 in one tick
+            const int ch1 = t + NP, ch2 = NP == 3 ? t + 2 : t + 2, ch3 = t + 1;
 #if RK_T4_STAMPS >= 2
             const long long tA = T4_NOW();
-            const int stg = ch1 % 3 == p ? 0 : ((ch2 >= 0 && ch2 % 3 == p) ? 1 : 2);
+            const int stg = ch1 % NP == p ? 0 : ((NP == 3 && ch2 >= 0 && ch2 % NP == p) ? 1 : 2);
 #endif
-            if (ch1 % 3 == p) {
+            if (ch1 % NP == p) {
                 // ---- stage 1 of chunk ch1: fetched tiles, next fetch, predict, T^T ----
                 if (ch1 < n_chunks) {
                     lds_dma_wait_all();
@@ -139,7 +170,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
                         buf[2 * k] = v.x; buf[2 * k + 1] = v.y;
                     }
                     lds_reads_done();
-                    if (ch1 + 3 < n_chunks) fetch(ch1 + 3);
+                    if (ch1 + NP < n_chunks) fetch(ch1 + NP);
 #pragma unroll
                     for (int i = 0; i < P; ++i) {
 #pragma unroll
@@ -161,7 +192,8 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
 #pragma unroll
                         for (int j = 0; j < P; ++j) X[i][j] = T[j][i];
                 }
-            } else if (ch2 >= 0 && ch2 % 3 == p) {
+            }
+            if (NP == 3 ? (ch1 % NP != p && ch2 >= 0 && ch2 % NP == p) : (ch1 % NP == p)) {
                 // ---- stage 2 of chunk ch2: LU of Sigma- with the forward sweep on T^T ----
                 if (ch2 < n_chunks) {
 #pragma unroll
@@ -170,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
                         for (int j = 0; j < P; ++j) A[i][j] = Sp[i][j];
                     lu_factor_fwd<P, P>(A, X, rpiv);
                 }
-            } else if (ch3 >= 0) {
+            } else if (ch1 % NP != p && ch3 >= 0 && (NP == 3 || ch3 % NP == p)) {
                 // ---- stage 3 of chunk ch3: back substitution, X = G^T (standard.py:176), hand-off ----
                 if (ch3 < n_chunks) {
                     lu_back<P, P>(A, X, rpiv);
@@ -220,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
 #endif
         }
 #if RK_T4_STAMPS >= 2
-        if (lane == 0) for (int k = 0; k < 4; ++k) dbg[blockIdx.x * 20 + 4 + p * 4 + k] = acc[k];
+        if (lane == 0) for (int k = 0; k < 4; ++k) dbg[tw * 20 + 4 + p * 4 + k] = acc[k];
 #endif
     } else {
         // ---------------- consumer ----------------
@@ -250,9 +282,8 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
             rvec1[k] = lds4_vec<TPW>(k, gl, 1, r) - k * TPW * ITEM4;
         }
         lds_barrier();                                               // Q | R of the blocks are in LDS
-        lds_barrier();                                               // tick -3
-        lds_barrier();                                               // tick -2
-        lds_barrier();                                               // tick -1: chunk 0 is in LDS
+#pragma unroll
+        for (int k = 0; k < NP; ++k) lds_barrier();                  // ticks -NP .. -1: chunk 0 is in LDS
 #ifdef RK_T4_STAMPS
         long long cacc[2] = {0, 0};
         const long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -351,14 +382,14 @@ __global__ void __launch_bounds__(256, 2) bwd_mv_tile4_kernel(SolveArgs a, doubl
             const long long tC = T4_NOW();
             cacc[0] += tB - tA; cacc[1] += tC - tB;
 #if RK_T4_STAMPS >= 3      // per-tick consumer work of the first 8 workgroups, behind the per-workgroup sums
-            if (blockIdx.x < 8 && t < 2048 && lane == 0) dbg[(size_t)gridDim.x * 20 + (size_t)blockIdx.x * 2048 + t] = tB - tA;
+            if (tw < 8 && t < 2048 && lane == 0) dbg[(size_t)gridDim.x * SETS * 20 + (size_t)tw * 2048 + t] = tB - tA;
 #endif
 #else
             lds_barrier();   
 #endif
         }
 #ifdef RK_T4_STAMPS
-        if (lane == 0) { dbg[blockIdx.x * 20] = cacc[0]; dbg[blockIdx.x * 20 + 1] = cacc[1]; dbg[blockIdx.x * 20 + 2] = n_chunks; dbg[blockIdx.x * 20 + 16] = rt0; dbg[blockIdx.x * 20 + 17] = __builtin_amdgcn_s_memrealtime(); dbg[blockIdx.x * 20 + 18] = ((long long)xcc << 32) | hwid; }
+        if (lane == 0) { dbg[tw * 20] = cacc[0]; dbg[tw * 20 + 1] = cacc[1]; dbg[tw * 20 + 2] = n_chunks; dbg[tw * 20 + 16] = rt0; dbg[tw * 20 + 17] = __builtin_amdgcn_s_memrealtime(); dbg[tw * 20 + 18] = ((long long)xcc << 32) | hwid; }
 #endif
     }
 }
@@ -418,39 +449,54 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     else rc = launch_fwd_tile4<HigherOrder>(h, c, a, tiles);
     if (rc || mode == RK_MODE_FILTER || a.N < 2) return rc;
     const int tpw = a.D == 3 ? 3 : 4;
-    const dim3 grid(div_up(a.B * a.D, tpw)), block(256);
+    // default: the 4-wave workgroups, two per CU; RK_T4_BWD=ds: 8-wave workgroups with each consumer alone on its SIMD (round 4's
+    // experiment, kept as an option: HW_ID stamps confirm the placement -- waves w and w + 4 share a SIMD, the consumers' partners
+    // have left -- and the consumer's tick stays at 3925 cycles against 3945, 245 per step, even with ONE set per CU
+    // (-DRK_T4_EXP=3): the step time is the consumer's own instruction stream, not a neighbour's; profiles/r04_c3_dedicated_simd.txt)
+    static const bool quad = [] { const char* e = getenv("RK_T4_BWD"); return !(e && e[0] == 'd'); }();
+    const int n_tw = div_up(a.B * a.D, tpw);
+    const dim3 grid(quad ? n_tw : div_up(n_tw, 2)), block(quad ? 256 : 512);
     LaunchTimer t(h, "bwd_mv_tile4_kernel");
 #ifdef RK_T4_STAMPS
     long long* dbg = nullptr;
-    RK_HIP(hipMalloc(&dbg, ((size_t)grid.x * 20 + 8 * 2048) * sizeof(long long)));
-    RK_HIP(hipMemsetAsync(dbg, 0, ((size_t)grid.x * 20 + 8 * 2048) * sizeof(long long), h->stream));
+    const unsigned n_slot = grid.x * (quad ? 1 : 2);            // one slot of 20 per tile-wave (set)
+    RK_HIP(hipMalloc(&dbg, ((size_t)n_slot * 20 + 8 * 2048) * sizeof(long long)));
+    RK_HIP(hipMemsetAsync(dbg, 0, ((size_t)n_slot * 20 + 8 * 2048) * sizeof(long long), h->stream));
 #define T4_DBG , dbg
 #else
 #define T4_DBG
 #endif
-    if (a.D == 1) hipLaunchKernelGGL((bwd_mv_tile4_kernel<1>), grid, block, 0, h->stream, a, tiles T4_DBG);
-    else if (a.D == 2) hipLaunchKernelGGL((bwd_mv_tile4_kernel<2>), grid, block, 0, h->stream, a, tiles T4_DBG);
-    else if (a.D == 3) hipLaunchKernelGGL((bwd_mv_tile4_kernel<3>), grid, block, 0, h->stream, a, tiles T4_DBG);
-    else hipLaunchKernelGGL((bwd_mv_tile4_kernel<4>), grid, block, 0, h->stream, a, tiles T4_DBG);
+#define RK_T4_BWD(D_)                                                                                                   \
+    do {                                                                                                                \
+        if (quad) hipLaunchKernelGGL((bwd_mv_tile4_kernel<D_, 3, 1>), grid, block, 0, h->stream, a, tiles T4_DBG);      \
+        else hipLaunchKernelGGL((bwd_mv_tile4_kernel<D_, 2, 2>), grid, block, 0, h->stream, a, tiles T4_DBG);           \
+    } while (0)
+    if (a.D == 1) RK_T4_BWD(1);
+    else if (a.D == 2) RK_T4_BWD(2);
+    else if (a.D == 3) RK_T4_BWD(3);
+    else RK_T4_BWD(4);
+#undef RK_T4_BWD
     t.stop();
     RK_HIP(hipGetLastError());
 #ifdef RK_T4_STAMPS
     {
-        std::vector<long long> hd((size_t)grid.x * 20 + 8 * 2048);
+        std::vector<long long> hd((size_t)n_slot * 20 + 8 * 2048);
         RK_HIP(hipMemcpyAsync(hd.data(), dbg, hd.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
         RK_HIP(hipStreamSynchronize(h->stream));
         RK_HIP(hipFree(dbg));
         double m[16] = {0};
-        for (unsigned w = 0; w < grid.x; ++w) for (int k = 0; k < 16; ++k) m[k] += (double)hd[w * 20 + k] / grid.x;
+        unsigned n_live = 0;
+        for (unsigned w = 0; w < n_slot; ++w) n_live += hd[w * 20 + 2] > 0;
+        for (unsigned w = 0; w < n_slot; ++w) for (int k = 0; k < 16; ++k) m[k] += (double)hd[w * 20 + k] / (n_live ? n_live : 1);
         const double nc = m[2] > 0 ? m[2] : 1;
-        fprintf(stderr, "[t4 stamps] per tick (mean over %u workgroups, %g ticks): consumer work %.0f wait %.0f |", grid.x, nc, m[0] / nc, m[1] / nc);
-        for (int p = 0; p < 3; ++p) fprintf(stderr, " producer %d: stage1 %.0f stage2 %.0f stage3 %.0f wait %.0f |", p, m[4 + 4 * p] * 3 / nc, m[5 + 4 * p] * 3 / nc, m[6 + 4 * p] * 3 / nc, m[7 + 4 * p] / nc);
+        fprintf(stderr, "[t4 stamps] per tick (mean over %u workgroups, %g ticks): consumer work %.0f wait %.0f |", n_slot, nc, m[0] / nc, m[1] / nc);
+        for (int p = 0; p < (quad ? 3 : 2); ++p) fprintf(stderr, " producer %d: stage1 %.0f stage2 %.0f stage3 %.0f wait %.0f |", p, m[4 + 4 * p] * (quad ? 3 : 2) / nc, m[5 + 4 * p] * (quad ? 3 : 2) / nc, m[6 + 4 * p] * (quad ? 3 : 2) / nc, m[7 + 4 * p] / nc);
         fprintf(stderr, "\n");
         long long t_min = hd[16], t_max = hd[17]; double life = 0;
         std::vector<int> per_cu(8 * 128, 0), simd_of(8 * 128, -1); int same_simd = 0, pairs = 0;
-        for (unsigned w = 0; w < grid.x; ++w) {
+        for (unsigned w = 0; w < n_slot; ++w) {
             t_min = std::min(t_min, hd[w * 20 + 16]); t_max = std::max(t_max, hd[w * 20 + 17]);
-            life += (double)(hd[w * 20 + 17] - hd[w * 20 + 16]) / grid.x;
+            life += (double)(hd[w * 20 + 17] - hd[w * 20 + 16]) / n_slot;
             const unsigned hw = (unsigned)hd[w * 20 + 18], xc = (unsigned)(hd[w * 20 + 18] >> 32) & 7;
             const unsigned cu = (hw >> 8) & 15, se = (hw >> 13) & 7;    // HW_ID: cu_id [11:8], sh [12], se [15:13]
             const unsigned simd = (hw >> 4) & 3;
@@ -464,10 +510,25 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
         fprintf(stderr, "[t4 stamps] kernel span %.1f us (100 MHz clock), mean workgroup lifetime %.1f us; workgroups per (xcc, se, cu): ", (t_max - t_min) / 100.0, life / 100.0);
         for (int k = 1; k < 8; ++k) if (hist[k]) fprintf(stderr, "%d CUs with %d, ", hist[k], k);
         fprintf(stderr, "consumer waves of a CU on the same SIMD: %d of %d pairs", same_simd, pairs);
+        {
+            int sh[4] = {0, 0, 0, 0};
+            for (unsigned w = 0; w < n_slot; ++w) if (hd[w * 20 + 2] > 0) sh[((unsigned)hd[w * 20 + 18] >> 4) & 3]++;
+            fprintf(stderr, "; consumers per SIMD id: %d %d %d %d", sh[0], sh[1], sh[2], sh[3]);
+            // SIMD of wave w relative to the SIMD of wave 0, over all workgroups (SETS = 2: waves 0-7)
+            const int nwv = quad ? 4 : 8;
+            std::vector<int> rel(nwv * 4, 0);
+            for (unsigned w = 0; w < n_slot; w += (quad ? 1 : 2)) {
+                const unsigned long long v = (unsigned long long)hd[w * 20 + 19];
+                if (!(v & 4)) continue;
+                for (int k = 0; k < nwv; ++k) if ((v >> (4 * k)) & 4) rel[k * 4 + (((v >> (4 * k)) & 3) - (v & 3) + 4) % 4]++;
+            }
+            fprintf(stderr, "\n[t4 stamps] SIMD of wave w minus SIMD of wave 0 (mod 4), counts of 0 1 2 3:");
+            for (int k = 0; k < nwv; ++k) fprintf(stderr, " w%d: %d %d %d %d |", k, rel[k * 4], rel[k * 4 + 1], rel[k * 4 + 2], rel[k * 4 + 3]);
+        }
 #if RK_T4_STAMPS >= 3
-        for (int w8 = 0; w8 < 8 && w8 < (int)grid.x; ++w8) {
+        for (int w8 = 0; w8 < 8 && w8 < (int)n_slot; ++w8) {
             std::vector<long long> v;
-            for (int t = 0; t < 2048; ++t) if (hd[(size_t)grid.x * 20 + w8 * 2048 + t] > 0) v.push_back(hd[(size_t)grid.x * 20 + w8 * 2048 + t]);
+            for (int t = 0; t < 2048; ++t) if (hd[(size_t)n_slot * 20 + w8 * 2048 + t] > 0) v.push_back(hd[(size_t)n_slot * 20 + w8 * 2048 + t]);
             if (v.empty()) continue;
             std::vector<long long> q = v; std::sort(q.begin(), q.end());
             fprintf(stderr, "\n[t4 stamps] workgroup %d consumer work per tick: min %lld p10 %lld p50 %lld p90 %lld max %lld; first ticks:", w8,
