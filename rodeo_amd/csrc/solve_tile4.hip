@@ -305,7 +305,11 @@ __global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_ke
                 // were the kernel's bound): each lane drops its element into the image of the time row, built in the
                 // LDS bytes of the step's own items (read by now), and every RPF steps one 16-byte-per-lane store
                 // writes RPF whole rows.
+#ifdef RK_T4_LOOKAHEAD
+                constexpr int LOOKAHEAD = RK_T4_LOOKAHEAD;
+#else
                 constexpr int LOOKAHEAD = 2;
+#endif
                 double Sp[CH4], Gt[CH4], Sf[CH4], mp[CH4], mf[CH4];
                 auto load = [&](int s) {
                     const char* q = in + roff[s & 3] + s * TPW * ITEM4;

@@ -20,7 +20,7 @@ def timeit(fn, dev, reps):
 
 
 def c3(args):
-    B, N, p = 512, 20000, 4
+    B, N, p = args.c3_batch, 20000, 4
     rng = np.random.default_rng(20241)
     theta = np.array([28., 10., 8. / 3.])
     W, init = ra.utils.first_order_pad(ra.ode.lorenz63, 3, p)
@@ -33,7 +33,7 @@ def c3(args):
     plan.mv(None); plan.dev.sync()
     kern = dict(plan.dev.profile_last())
     plan.dev.profile_enable(False)
-    return {"config": "C3 Lorenz63 d=3 p=4 N=20000 B=512 solve_mv+kramer", "ms": ms, "traj_steps_per_s": B * N / ms * 1e3,
+    return {"config": "C3 Lorenz63 d=3 p=4 N=20000 B=%d solve_mv+kramer" % B, "ms": ms, "traj_steps_per_s": B * N / ms * 1e3,
             "hbm_frac_solve": a * B * N / (ms * 1e-3) / 8e12, "layout": plan.layout, "kernels_ms": kern}
 
 
@@ -134,6 +134,7 @@ def c5(args):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["c3", "c4", "c5"])
+    ap.add_argument("--c3-batch", type=int, default=512)
     ap.add_argument("--c5-batch", type=int, default=256)
     ap.add_argument("--c5-steps", type=int, default=2000)      # BASELINE config 5: N = 2000
     ap.add_argument("--c5-itg", default="kramer", choices=["kramer", "rodeo", "schober"])
