@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # HBM traffic of the two headline kernels from this command's rocprofv3 --pmc passes (scripts/collect_profiles.sh): the
 # committed file `roofline.traffic` is read from -- named, so that counter files of other workloads can never be picked up
-PMC_TRAFFIC_FILE = "r03d_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"
 N_STEPS, N_TRAJ, T_MAX, P, D = 4000, 1024, 40.0, 3, 2
 
 

@@ -15,5 +15,5 @@ done
 wait
 for k in "$@"; do
   n=$(echo $k | tr '=,' '__')
-  /opt/rocm/bin/hipcc $(ls build/*.o | grep -v "solve_tile3\|_stamps\|_abl") build/solve_tile3_abl_$n.o -shared -fPIC --offload-arch=gfx950 -L/opt/rocm/lib -lrccl -lhiprtc -Wl,-rpath,/opt/rocm/lib -o ../librodeo_kalman_abl_$n.so
+  /opt/rocm/bin/hipcc $(for f in *.hip; do [ "$f" != solve_tile3.hip ] && echo build/${f%.hip}.o; done) build/solve_tile3_abl_$n.o -shared -fPIC --offload-arch=gfx950 -L/opt/rocm/lib -lrccl -lhiprtc -Wl,-rpath,/opt/rocm/lib -o ../librodeo_kalman_abl_$n.so
 done

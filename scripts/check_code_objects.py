@@ -119,6 +119,8 @@ def check(kernels):
         if k.get("group_segment_fixed_size", 0) > LDS_LIMIT:
             problems.append(f"{nm}: {k['group_segment_fixed_size']} B of LDS (limit {LDS_LIMIT})")
         for key, need in MIN_WORKGROUPS_PER_CU.items():
+            if key in k["name"] and k.get("max_flat_workgroup_size", 1024) > 256:
+                need = 1                       # the 8-wave two-set form of the kernel (SETS = 2): one workgroup per CU by design
             if key in k["name"] and workgroups_per_cu(k) < need:
                 problems.append(f"{nm}: {workgroups_per_cu(k)} workgroup(s) per CU (registers "
                                 f"{k.get('vgpr_count', 0) + k.get('agpr_count', 0)}, LDS {k.get('group_segment_fixed_size', 0)} B); "
