@@ -19,11 +19,29 @@ __shared__ __attribute__((aligned(16))) double g_lds[8192];
 //     6: 0 with the subtraction folded away (Ss chain: two MFMAs back to back)
 //     7: one MFMA per step (dependent chain of single MFMAs): the latency of one v_mfma_f64_4x4x4_4b
 //     8: one v_add_f64 per step (dependent): VALU fp64 latency
-template <int VAR>
-__global__ void __launch_bounds__(64) k(double* out, long long* cyc, double seed) {
-    const int lane = threadIdx.x;
-    for (int e = lane; e < 8192; e += 64) g_lds[e] = 1e-3 * (e % 97) * seed;
+__shared__ volatile int g_stop;
+__shared__ __attribute__((aligned(16))) double g_noise[3 * 3840];
+// NOISE: waves 1..3 of the workgroup imitate the producers' LDS traffic while the chain runs: per "tick" 56 ds_write_b64 and 20
+// ds_read_b64 per lane (the hand-off and the landing-zone reads of solve_tile4.hip's producers), then PAUSE cycles of sleep
+template <int VAR, int NOISE>
+__global__ void __launch_bounds__(NOISE ? 256 : 64) k(double* out, long long* cyc, double seed) {
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) g_stop = 0;
+    for (int e = threadIdx.x; e < 8192; e += blockDim.x) g_lds[e] = 1e-3 * (e % 97) * seed;
     __syncthreads();
+    if (NOISE && threadIdx.x >= 64) {
+        double* mine = g_noise + (threadIdx.x >> 6) * 3840 - 3840 + lane;
+        double acc = seed;
+        while (g_stop == 0) {
+#pragma unroll
+            for (int i = 0; i < 56; ++i) mine[(i % 60) * 64] = acc + i;
+#pragma unroll
+            for (int i = 0; i < 20; ++i) acc += mine[(i % 60) * 64];
+            if (NOISE > 1) __builtin_amdgcn_s_sleep(NOISE);
+        }
+        out[blockIdx.x * 256 + threadIdx.x] = acc;
+        return;
+    }
     double Ss = 1.0 + 1e-3 * lane, ms = 0.5;
     const bool valid = (lane >> 4) < 3, st_m = valid && (lane & 3) == 0;
     const double* rd = g_lds + lane;
@@ -57,15 +75,16 @@ __global__ void __launch_bounds__(64) k(double* out, long long* cyc, double seed
         if (VAR == 4) __syncthreads();
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * 64 + lane] = Ss + ms;
+    if (lane == 0) g_stop = 1;
+    out[blockIdx.x * 256 + lane] = Ss + ms;
     if (lane == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int VAR>
+template <int VAR, int NOISE = 0>
 void run(const char* name) {
     double* out; long long* cyc;
-    hipMalloc(&out, 256 * 64 * 8); hipMalloc(&cyc, 256 * 8);
-    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL(k<VAR>, dim3(256), dim3(64), 0, 0, out, cyc, 1.0);
+    hipMalloc(&out, 256 * 256 * 8); hipMalloc(&cyc, 256 * 8);
+    for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((k<VAR, NOISE>), dim3(256), dim3(NOISE ? 256 : 64), 0, 0, out, cyc, 1.0);
     hipDeviceSynchronize();
     std::vector<long long> h(256);
     hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
@@ -83,5 +102,9 @@ int main() {
     run<2>("+ exec-masked image writes (as in the kernel)");
     run<3>("+ five LDS reads per step, two steps ahead");
     run<4>("+ a workgroup barrier per 16 steps");
+    run<3, 1>("the same + three waves writing / reading LDS back to back");
+    run<3, 8>("the same + three waves at ~ the producers' LDS rate (bursts, sleep 8)");
+    run<3, 32>("the same + three waves, bursts with sleep 32");
+    run<0, 1>("registers-only step + three waves writing / reading LDS back to back");
     return 0;
 }
