@@ -41,6 +41,28 @@ __device__ __forceinline__ int lds4_vec(int s, int g, int which, int rr) {
     return (s * TPW + g) * ITEM4 + 384 + (vec_slot(s, g, which, rr) << 3);
 }
 
+// The consumer's image of a time row (round 4): every lane drops its Sigma element into a 64-double array and its mean element
+// into a second one, 512 bytes behind, inside the step's LDS bytes -- two unmasked stores off one address that go out as ONE
+// ds_write2_b64, where two exec-masked ds_write_b64 to the row format stood (probe15: the two masked writes cost the chain 57
+// cycles per step) -- and whoever sends the row to memory gathers the 16-byte pieces of the row format (per tile 16 Sigma doubles,
+// then 4 mean doubles) from them: a Sigma piece is two neighbouring doubles of the first array, a mean piece two doubles 128 bytes
+// apart in the second.  Lane = 16 r + 4 g + c (t4_coord); the mean is in row form (the lanes c = 0 hold the row's value).
+// o0, o1: byte offsets of the piece's two doubles inside the step's image.
+constexpr int T4_IMG_MEAN = 512;
+__device__ __forceinline__ void t4_piece_offsets(int fcol_bytes, int& o0, int& o1) {
+    const int gq = fcol_bytes / (T4_DOUBLES * 8), off = fcol_bytes - gq * (T4_DOUBLES * 8);
+    if (off < 128) {
+        const int idx0 = off >> 3, r = idx0 >> 2, c0 = idx0 & 3;
+        o0 = (16 * r + 4 * gq + c0) * 8;
+        o1 = o0 + 8;
+    } else {
+        const int r0 = (off - 128) >> 3;
+        o0 = T4_IMG_MEAN + (16 * r0 + 4 * gq) * 8;
+        o1 = o0 + 128;
+    }
+}
+typedef double t4_d2 __attribute__((ext_vector_type(2)));
+
 #ifdef RK_T4_STAMPS   // experiment build: per-workgroup cycle sums (consumer work / barrier wait, producer stages / wait)
 #define T4_STAMP_ARG , long long* __restrict__ dbg
 #define T4_NOW() __builtin_amdgcn_s_memtime()
@@ -60,6 +82,10 @@ __global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_ke
     // time steps per hand-off: 16 with three tiles per wave, 12 with four -- 74 KiB of LDS either way, so that TWO
     // workgroups share a CU (with 16 steps x 4 tiles: 96 KiB, one workgroup per CU, the chain waves idle half the time)
     constexpr int CH4 = TPW == 3 ? 16 : 12;
+    // the consumer's image of a time row: two dense arrays (t4_piece_offsets) with three tiles per wave; the row format itself, written
+    // by exec-masked stores a step late, with four (measured: the dense image costs the four-tile shape 5 %, the masked one the
+    // three-tile shape 10 %)
+    constexpr bool DENSE_IMG = TPW == 3;
     constexpr int BUF = CH4 * TPW * ITEM4;                         // 24 KiB
     constexpr int ROW_BYTES = TPW * T4_DOUBLES * 8;                // this tile-wave's bytes per time row: 480 / 640
     constexpr int N_DMA = (CH4 * ROW_BYTES / 16 + 63) / 64;        // 1-KiB LDS-DMA pieces per chunk: 8 / 10
@@ -128,12 +154,14 @@ __global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_ke
         // landing zone = image of the chunk's 16 time rows x ROW_BYTES; piece j = 64 i + lane (clamped in the last one)
         char* const zone = zones + p * ZONE;
         const unsigned zone_lds = __builtin_amdgcn_readfirstlane(lds_addr(zone));
-        int frow[N_DMA], fcol[N_DMA];
+        int frow[N_DMA], fcol[N_DMA], po0[N_DMA], po1[N_DMA];
 #pragma unroll
         for (int i = 0; i < N_DMA; ++i) {
             int j = 64 * i + lane;
             j = j < CH4 * ROW_BYTES / 16 ? j : CH4 * ROW_BYTES / 16 - 1;
             frow[i] = j / (ROW_BYTES / 16); fcol[i] = (j % (ROW_BYTES / 16)) * 16;
+            t4_piece_offsets(fcol[i], po0[i], po1[i]);
+            po0[i] += frow[i] * (TPW * ITEM4); po1[i] += frow[i] * (TPW * ITEM4);
         }
         auto fetch = [&](int ch) {
             const int n_hi = a.N - 1 - ch * CH4;
@@ -186,26 +214,43 @@ __global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_ke
                         R[(2 * k) / P][(2 * k) % P] = r2.x; R[(2 * k + 1) / P][(2 * k + 1) % P] = r2.y;
                     }
                     predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
-                    mm_nt<P, P, P>(Sf, Q, T);                        // T = Sigma_f Q^T          (standard.py:175)
+                    if constexpr (NP != 3) {
+                        mm_nt<P, P, P>(Sf, Q, T);                    // T = Sigma_f Q^T          (standard.py:175)
 #pragma unroll
-                    for (int i = 0; i < P; ++i)
+                        for (int i = 0; i < P; ++i)
 #pragma unroll
-                        for (int j = 0; j < P; ++j) X[i][j] = T[j][i];
+                            for (int j = 0; j < P; ++j) X[i][j] = T[j][i];
+                    }
                 }
             }
             if (NP == 3 ? (ch1 % NP != p && ch2 >= 0 && ch2 % NP == p) : (ch1 % NP == p)) {
-                // ---- stage 2 of chunk ch2: LU of Sigma- with the forward sweep on T^T ----
+                // ---- stage 2 of chunk ch2: T^T, LU of Sigma- with the forward sweep on T^T, back substitution ----
+                // (round 4: with the consumer's tick down to ~2.9 k cycles the LONGEST producer stage sets the tick -- three stages of
+                //  3.3 / 1.5 / 4.4 k; T^T moved here from stage 1 and the back substitution from stage 3: ~2.7 / 2.9 / 3.0 k)
                 if (ch2 < n_chunks) {
+                    if constexpr (NP == 3) {
+                        double T[P][P], Q[P][P];
+#pragma unroll
+                        for (int k = 0; k < P * P / 2; ++k) {
+                            const double2 q2 = *(const double2*)(my_qr + 2 * k);
+                            Q[(2 * k) / P][(2 * k) % P] = q2.x; Q[(2 * k + 1) / P][(2 * k + 1) % P] = q2.y;
+                        }
+                        mm_nt<P, P, P>(Sf, Q, T);                    // T = Sigma_f Q^T          (standard.py:175)
+#pragma unroll
+                        for (int i = 0; i < P; ++i)
+#pragma unroll
+                            for (int j = 0; j < P; ++j) X[i][j] = T[j][i];
+                    }
 #pragma unroll
                     for (int i = 0; i < P; ++i)
 #pragma unroll
                         for (int j = 0; j < P; ++j) A[i][j] = Sp[i][j];
                     lu_factor_fwd<P, P>(A, X, rpiv);
+                    lu_back<P, P>(A, X, rpiv);                       // X = G^T (standard.py:176)
                 }
             } else if (ch1 % NP != p && ch3 >= 0 && (NP == 3 || ch3 % NP == p)) {
-                // ---- stage 3 of chunk ch3: back substitution, X = G^T (standard.py:176), hand-off ----
+                // ---- stage 3 of chunk ch3: the finished image of chunk ch3 - 2 to memory, hand-off of this chunk ----
                 if (ch3 < n_chunks) {
-                    lu_back<P, P>(A, X, rpiv);
                     // the smoothed rows of chunk ch3 - 2: the consumer built their image in the buffer this wave is
                     // about to refill (LDS operations of one wave execute in order); 16 bytes per lane, whole rows
                     if (ch3 >= 2 && buffer_ok) {
@@ -216,7 +261,15 @@ __global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_ke
                         for (int i0 = 0; i0 < N_DMA; i0 += 4) {
                             u32x4 v[4];
 #pragma unroll
-                            for (int i = i0; i < i0 + 4 && i < N_DMA; ++i) v[i - i0] = *(const u32x4*)(img + frow[i] * (TPW * ITEM4) + fcol[i]);
+                            for (int i = i0; i < i0 + 4 && i < N_DMA; ++i) {
+                                if constexpr (DENSE_IMG) {
+                                    t4_d2 pr;
+                                    pr.x = *(const double*)(img + po0[i]); pr.y = *(const double*)(img + po1[i]);
+                                    v[i - i0] = __builtin_bit_cast(u32x4, pr);
+                                } else {
+                                    v[i - i0] = *(const u32x4*)(img + frow[i] * (TPW * ITEM4) + fcol[i]);
+                                }
+                            }
 #pragma unroll
                             for (int i = i0; i < i0 + 4 && i < N_DMA; ++i) {
                                 const int vo = tw * TPW + fcol[i] / (T4_DOUBLES * 8) < n_tiles
@@ -268,12 +321,16 @@ __global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_ke
         const int chunk_span = (int)((CH4 - 1) * row_bytes + ROW_BYTES);
         // row images for the 16-byte stores: lane = piece fj of row fr of a group of RPF rows (10 pieces per tile)
         constexpr int PIECES = ROW_BYTES / 16, RPF = 64 / PIECES, NFL = CH4 / RPF;
-        static_assert(CH4 % RPF == 0 && ROW_BYTES <= TPW * ITEM4, "row images live inside the step's items");
+        static_assert(CH4 % RPF == 0 && 64 * 16 <= TPW * ITEM4, "the 64 pair slots of a step live inside the step's items");
         const int fj = lane % PIECES, fr = lane / PIECES;
         const bool fvalid = fr < RPF && tw * TPW + fj / 10 < n_tiles;
+        int f_o0, f_o1;
+        t4_piece_offsets(fj * 16, f_o0, f_o1);
+        f_o0 = fvalid ? fr * TPW * ITEM4 + f_o0 : 0; f_o1 = fvalid ? fr * TPW * ITEM4 + f_o1 : 8;
         const int f_lds = fvalid ? fr * TPW * ITEM4 + fj * 16 : 0;
+        const int wP = lane * 8;                                    // this lane's Sigma element in a step's image; its mean element T4_IMG_MEAN behind
+        const int wS = gl * (T4_DOUBLES * 8) + idx * 8, wM = gl * (T4_DOUBLES * 8) + 128 + r * 8;      // (row format)
         const int f_vo = fvalid && buffer_ok ? (int)((RPF - 1 - fr) * row_bytes) + fj * 16 : (int)0x80000000;
-        const int wS = gl * (T4_DOUBLES * 8) + idx * 8, wM = gl * (T4_DOUBLES * 8) + 128 + r * 8;
         int roff[4], rvec[4], rvec1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -343,13 +400,21 @@ __global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_ke
                     }
                     ms = MF(Gt[s], ms - mp[s], mf[s]);                  // mu_f + G (mu_s - mu-)     (standard.py:213-214)
                     Ss = MF(V1, Gt[s], Sf[s]);                          // Sigma_f + G D G^T         (standard.py:215-216)
-                    if (TPW != 4 || s == CH4 - 1) {
-                        if (tc.valid) *(double*)(img + s * TPW * ITEM4 + wS) = Ss;  // (exec-masked: measured faster than
-                        if (st_m) *(double*)(img + s * TPW * ITEM4 + wM) = ms;      // sending idle lanes to a dump slot)
+                    if constexpr (DENSE_IMG) {
+                        *(double*)(img + s * TPW * ITEM4 + wP) = Ss;             // all lanes, both stores in one ds_write2_b64
+                        *(double*)(img + s * TPW * ITEM4 + wP + T4_IMG_MEAN) = ms;  // (idle tile slots land in unused bytes)
+                    } else if (s == CH4 - 1) {
+                        if (tc.valid) *(double*)(img + s * TPW * ITEM4 + wS) = Ss;
+                        if (st_m) *(double*)(img + s * TPW * ITEM4 + wM) = ms;
                     }
                     if (TPW != 4 && (s + 1) % RPF == 0 && self_flush) {
                         const int k = s / RPF;
-                        fl[k] = *(const u32x4*)(img + (s - (RPF - 1)) * TPW * ITEM4 + f_lds);
+                        {
+                            t4_d2 pr;
+                            pr.x = *(const double*)(img + (s - (RPF - 1)) * TPW * ITEM4 + f_o0);
+                            pr.y = *(const double*)(img + (s - (RPF - 1)) * TPW * ITEM4 + f_o1);
+                            fl[k] = __builtin_bit_cast(u32x4, pr);
+                        }
                         if (k >= 1)
                             __builtin_amdgcn_raw_buffer_store_b128(fl[k - 1], rsrc, f_vo, (int)((CH4 - s + RPF - 1) * row_bytes), 0);
                     }
@@ -359,7 +424,7 @@ __global__ void __launch_bounds__(256 * SETS, SETS == 1 ? 2 : 1) bwd_mv_tile4_ke
                     if constexpr (TPW == 4) {                       // (rows are complete only now: their writes run a step late)
 #pragma unroll
                         for (int k = 0; k < NFL; ++k) {
-                            const u32x4 v = *(const u32x4*)(img + k * RPF * TPW * ITEM4 + f_lds);
+                            const u32x4 v = *(const u32x4*)(img + k * RPF * TPW * ITEM4 + f_lds);      // (TPW = 4: the row format)
                             __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, f_vo, (int)((CH4 - (k + 1) * RPF) * row_bytes), 0);
                         }
                     } else {
@@ -453,11 +518,14 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     else rc = launch_fwd_tile4<HigherOrder>(h, c, a, tiles);
     if (rc || mode == RK_MODE_FILTER || a.N < 2) return rc;
     const int tpw = a.D == 3 ? 3 : 4;
-    // default: the 4-wave workgroups, two per CU; RK_T4_BWD=ds: 8-wave workgroups with each consumer alone on its SIMD (round 4's
-    // experiment, kept as an option: HW_ID stamps confirm the placement -- waves w and w + 4 share a SIMD, the consumers' partners
-    // have left -- and the consumer's tick stays at 3925 cycles against 3945, 245 per step, even with ONE set per CU
-    // (-DRK_T4_EXP=3): the step time is the consumer's own instruction stream, not a neighbour's; profiles/r04_c3_dedicated_simd.txt)
-    static const bool quad = [] { const char* e = getenv("RK_T4_BWD"); return !(e && e[0] == 'd'); }();
+    // Two shapes of workgroup (RK_T4_BWD=quad|ds forces one).  quad: 4 waves, two workgroups per CU.  ds: 8 waves carrying two sets, each
+    // consumer alone on its SIMD -- built in round 4 to see whether the chain wave suffers from its SIMD partner: it does not (HW_ID stamps
+    // confirm the placement, and the consumer's tick stayed at 3925 cycles against 3945, 245 per step, even with ONE set per CU,
+    // profiles/r04_c3_dedicated_simd.txt).  What shortened the step was the dense image (one ds_write2_b64 per step: 245 -> 190 cycles);
+    // with it the three-tile shape runs 2.22 ms in ds against 2.79 in quad (C3), the four-tile shape 0.57 in quad against 0.68 in ds
+    // (FitzHugh-Nagumo, n_deriv 4): the default follows the shape.
+    static const int forced = [] { const char* e = getenv("RK_T4_BWD"); return e && e[0] == 'd' ? 2 : (e && e[0] == 'q' ? 1 : 0); }();
+    const bool quad = forced ? forced == 1 : tpw != 3;
     const int n_tw = div_up(a.B * a.D, tpw);
     const dim3 grid(quad ? n_tw : div_up(n_tw, 2)), block(quad ? 256 : 512);
     LaunchTimer t(h, "bwd_mv_tile4_kernel");
