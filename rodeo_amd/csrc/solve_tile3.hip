@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
 #pragma unroll
                 for (int j = 0; j < P; ++j) { qr[g * QR_STRIDE + i * P + j] = Q0[i][j]; qr[g * QR_STRIDE + 9 + i * P + j] = R0[i][j]; }
         }
-        __syncthreads();                                           // (matched by the consumer's first barrier)
+        lds_barrier();                                           // (matched by the consumer's first barrier)
         const double* const my_qr = qr + g * QR_STRIDE;
         auto load_q = [&](double (&Qv)[P][P]) {
 #pragma unroll
@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();                                          // (LDS only: the DMA prefetch of three ticks ahead stays in flight)
         }
     } else {
         // ---------------- consumer ----------------
@@ -616,11 +616,11 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
             rvec1[k] = sim_vec_byte(k, g, 1, r) - k * 4 * SIM_ITEM;
         }
         double x = 0.0;
-        __syncthreads();                                            // Q | R of the tiles (and the observations) are in LDS
+        lds_barrier();                                            // Q | R of the tiles (and the observations) are in LDS
         int next_n = LP ? next_index() : -1;
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
+        lds_barrier();
+        lds_barrier();
+        lds_barrier();
         for (int t = 0; t < n_chunks; ++t) {
             const char* in = lds_raw + (t & 1) * SIM_BUF;
             const int n_hi = a.N - t * CHUNK;
@@ -647,6 +647,7 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
                     x = MF(Gt, x - mp, mfw);
                     u32x2 bits;
                     __builtin_memcpy(&bits, &x, 8);
+                    // (only the log-posterior wanted, a.x = NULL: the store stays, out of range -- a uniform branch around it cost 6 us)
                     __builtin_amdgcn_raw_buffer_store_b64(bits, rsrc, xvo, (int)((CHUNK - 1 - s) * xstride * sizeof(double)), 0);
                     if constexpr (LP) xs[s] = x;
                 }
@@ -677,7 +678,7 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
                     --n_cur;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         // x[0] = ode_init exactly (solve.py:196-204): the mean column of tile time 0
         const double x_init = tiles[(size_t)tc.tau * TILE_DOUBLES + r * 4 + 3];
