@@ -533,7 +533,11 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
                         predict_block<P>(Q, R, mf, Sf, mp, Sp);          // pred[n+1] from filt[n]   (standard.py:57-59)
                     }
                     const int n = a.N - ch1 * CHUNK - s;
+#ifdef RK_T3_ABLATE_SIMZ                                       // experiment builds (scripts/c4_ablation.sh): the sampler without its generator
+                    z[0] = 0.25 + 1e-3 * n; z[1] = -0.5;
+#else
                     normal_pair(a.seed, traj, (uint32_t)(n < 1 ? 1 : n), (uint32_t)blk, PURPOSE_SMOOTH, 0u, z[0], z[1]);
+#endif
                 }
             } else if (ch2 >= 0 && ch2 % 3 == p) {
                 // ---- stage 2 of chunk ch2: T (standard.py:175), LU of Sigma- with the forward sweep, the third normal ----
@@ -550,7 +554,11 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
                     lu_factor_fwd<P, P>(A, X, rpiv);
                     const int n = a.N - ch2 * CHUNK - s;
                     double z3;
+#ifdef RK_T3_ABLATE_SIMZ
+                    z[2] = 0.125 + 1e-3 * n; z3 = 0.0;
+#else
                     normal_pair(a.seed, traj, (uint32_t)(n < 1 ? 1 : n), (uint32_t)blk, PURPOSE_SMOOTH, 1u, z[2], z3);
+#endif
                 }
             } else if (ch3 >= 0) {
                 // ---- stage 3 of chunk ch3: G (standard.py:176), the conditional draw (standard.py:248-254), hand-off ----
@@ -568,7 +576,14 @@ __global__ void __launch_bounds__(256, 2) bwd_sim_tile3_kernel(SolveArgs a, doub
                     for (int i = 0; i < P; ++i)
 #pragma unroll
                         for (int j = 0; j < P; ++j) Ssim[i][j] = Sf[i][j] - GT[i][j];   // standard.py:253-254
+#ifdef RK_T3_ABLATE_SIMPSD                                     // ... and without the factor of the conditional variance
+#pragma unroll
+                    for (int i = 0; i < P; ++i)
+#pragma unroll
+                        for (int j = 0; j < P; ++j) L[i][j] = Ssim[i][j];
+#else
                     psd_factor<P>(Ssim, L);
+#endif
                     if (n >= 1) {
                         char* o = lds_raw + (ch3 & 1) * SIM_BUF;
 #pragma unroll

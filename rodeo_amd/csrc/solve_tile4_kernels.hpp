@@ -74,6 +74,10 @@ __global__ void __launch_bounds__(64) fwd_tile4_kernel(SolveArgs a, double* __re
             __builtin_amdgcn_raw_buffer_store_b64(bM, rsrc, voM, 0, 0);
         };
         // (the state of time n is stored one step late, behind the first MFMA of step n + 1: solve_tile3_kernels.hpp)
+        // (round 4: the step written in "issue order" -- the covariance chain U -> S-^T -> Z -> S_c -> 1 / S_c first, every MFMA as soon as
+        //  its operand is back, the offset's DPP moves and FMAs between the links of the reciprocal, pinned with sched_barrier(0) -- took
+        //  372 cycles per step against hipcc's own order's 307: the in-order model "17 cycles of issue, 29 of latency per MFMA" that
+        //  explains the chains of probe15 does not predict the mixed MFMA / VALU stream; left to the compiler)
         for (int n = 0; n < a.N; ++n) {
             const double U = MF(S, Qt, 0.0);
             asm volatile("" :: "v"(U) : "memory");                   // (the stores stay behind U; no copy of m, which lives on)

@@ -27,12 +27,12 @@ if [ "$part" = a ]; then
   prof c3_fetch --pmc FETCH_SIZE --output-format csv -d $out/${tag}_c3_fetch -o fetch -- python3 $root/scripts/bench_configs.py c3
   prof c3_write --pmc WRITE_SIZE --output-format csv -d $out/${tag}_c3_write -o write -- python3 $root/scripts/bench_configs.py c3
   # C4 forward step: what the generator and the square root cost (experiment builds of scripts/c4_ablation.sh, results wrong by construction)
-  for abl in RK_T3_ABLATE_1 RK_T3_ABLATE_2; do
+  for abl in RK_T3_ABLATE_1 RK_T3_ABLATE_2 RK_T3_ABLATE_SIMZ; do
     if [ -f rodeo_amd/librodeo_kalman_abl_$abl.so ]; then
       RK_LIB_PATH=$root/rodeo_amd/librodeo_kalman_abl_$abl.so python3 scripts/bench_configs.py c4 > $out/${tag}_c4_$abl.jsonl 2> $out/${tag}_c4_$abl.err || true
     fi
   done
-  RK_T4_BWD=ds python3 scripts/bench_configs.py c3 > $out/${tag}_c3_ds.jsonl 2> $out/${tag}_c3_ds.err
+  RK_T4_BWD=quad python3 scripts/bench_configs.py c3 > $out/${tag}_c3_quad.jsonl 2> $out/${tag}_c3_quad.err
   python3 scripts/nderiv_times.py > $out/${tag}_nderiv_times.jsonl 2> $out/${tag}_nderiv_times.err
   python3 scripts/block_vs_dense_times.py > $out/${tag}_block_vs_dense.jsonl 2> $out/${tag}_block_vs_dense.err || true
 else

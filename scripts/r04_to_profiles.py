@@ -77,7 +77,7 @@ for c, (B, N, d, p, per) in {"c3": (512, 20000, 3, 4, 3 * 3 * 4 * 5 * 8), "c4": 
         json.dump(o, open(f"{P}/r04_{c}_pmc_traffic{suf}.json", "w"), indent=1)
         print("  ", f"r04_{c}_pmc_traffic{suf}.json")
 lines = []
-for f in (f"{tag}_configs_c3_c4.jsonl", f"{tag}_c3_ds.jsonl", f"{tag}_c4_unfused.jsonl", f"{tag}_c5_standard_full.json", f"{tag}_c5_sqrt_full.json",
+for f in (f"{tag}_configs_c3_c4.jsonl", f"{tag}_c3_quad.jsonl", f"{tag}_c4_unfused.jsonl", f"{tag}_c5_standard_full.json", f"{tag}_c5_sqrt_full.json",
           f"{tag}_c5_N50.json", f"{tag}_c5_regs_lu_N50.json"):
     fp = os.path.join(G, f)
     if os.path.exists(fp):
@@ -94,7 +94,8 @@ copy(f"{G}/{tag}_block_vs_dense.jsonl", f"r04_block_vs_dense_32var_ring{suf}.jso
 # C4 forward step: cycles per step of the chkrebtii forward kernel with parts removed
 rows = []
 for name, f in (("shipped kernel", f"{tag}_configs_c3_c4.jsonl"), ("no generator (z constant)", f"{tag}_c4_RK_T3_ABLATE_1.jsonl"),
-                ("no generator, no square root", f"{tag}_c4_RK_T3_ABLATE_2.jsonl")):
+                ("no generator, no square root", f"{tag}_c4_RK_T3_ABLATE_2.jsonl"),
+                ("sampler without ITS generator", f"{tag}_c4_RK_T3_ABLATE_SIMZ.jsonl")):
     fp = os.path.join(G, f)
     if os.path.exists(fp):
         for ln in open(fp):
