@@ -749,7 +749,9 @@ constexpr int BS_T = 10, BS_Q = (BS_T * BS_T + NWAVE - 1) / NWAVE;
 // the LU below is its upper / non-transposed case)
 template <bool LOWER>
 __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int trans_, double* Bm_, int ldb_, int n_, int nr_,
-                                               double* ws_end_ = nullptr);
+                                               double* ws_end_ = nullptr, const double* dm_ = nullptr, double* mu_ = nullptr);
+// the sizes at which wg_lu_solve ends in wg_tri_solve_regs (and can take the smoother's mean update along)
+__device__ __forceinline__ bool lu_backsub_in_regs(int n, int nr) { return n > 64 && n <= 16 * BS_T && nr <= 16 * BS_T && DT == 512; }
 
 }  // namespace rk
 #include "solve_dense_lu_regs.hpp"
@@ -758,7 +760,7 @@ namespace rk {
 // regs_: the forward elimination with [A | Bm] resident in registers (solve_dense_lu_regs.hpp) where the sizes allow it;
 // 0 = always the panel loop over global memory below (RK_DENSE_LU=global: the bit-equality test's other leg)
 __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int ldb_, int n_, int nr_, int* piv_,
-                                         double* ws_end_ = nullptr, int regs_ = 1) {
+                                         double* ws_end_ = nullptr, int regs_ = 1, const double* dm_ = nullptr, double* mu_ = nullptr) {
     double* const lds = g_lds;
     auto* const A = uni_g(A_);
     auto* const Bm = uni_g(Bm_);
@@ -771,7 +773,7 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         RK_STAMP_RESET();
         wg_lu_fwd_regs((double*)A, lda, (double*)Bm, ldb, n, nr, (double*)ws_end);
         RK_STAMP_RESET();
-        wg_tri_solve_regs<false>((const double*)A, lda, 0, (double*)Bm, ldb, n, nr);
+        wg_tri_solve_regs<false>((const double*)A, lda, 0, (double*)Bm, ldb, n, nr, nullptr, dm_, mu_);
         RK_STAMP(5);
         return;
     }
@@ -955,8 +957,8 @@ __device__ __noinline__ void wg_lu_solve(double* A_, int lda_, double* Bm_, int 
         __syncthreads();
         RK_STAMP(4);
     }
-    if (n > 64 && n <= 16 * BS_T && nr <= 16 * BS_T && DT == 512) {     // right-hand side resident in registers
-        wg_tri_solve_regs<false>((const double*)A, lda, 0, (double*)Bm, ldb, n, nr, (double*)ws_end);
+    if (lu_backsub_in_regs(n, nr)) {                                    // right-hand side resident in registers
+        wg_tri_solve_regs<false>((const double*)A, lda, 0, (double*)Bm, ldb, n, nr, (double*)ws_end, dm_, mu_);
         RK_STAMP_RESET();
         return;
     }
@@ -1520,10 +1522,12 @@ __global__ void __launch_bounds__(DT) dense_bwd_mv_kernel(DenseArgs a) {
                     for (int i = threadIdx.x; i < p; i += DT) w.dm[i] = mu_s[i] - w.mup[i];
                     __syncthreads();
                     RK_STAMP(0);
-                    wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv, a.ws + a.ws_stride, a.lu_regs);   // A3 <- G^T
+                    const bool mean_fused = lu_backsub_in_regs(p, p);       // (the back substitution takes mu_f + G dm along)
+                    wg_lu_solve(w.A2, p, w.A3, p, p, p, w.piv, a.ws + a.ws_stride, a.lu_regs, mean_fused ? w.dm : nullptr,
+                                mean_fused ? mu_f : nullptr);                    // A3 <- G^T
                     RK_STAMP_RESET();
                     // mean: mu_f + G dm, the column sums of G^T split over the workgroup (partial sums through LDS)
-                    {
+                    if (!mean_fused) {
                         const int ng = DT / 64;                                     // row groups of G^T
                         for (int i = threadIdx.x & 63; i < p; i += 64) {
                             const int gq = threadIdx.x >> 6;

@@ -461,11 +461,16 @@ __device__ __noinline__ void tri_trsm_all(int k0_, int nb_, int nct_) {
 // (Two ways of hiding the per-block global round trip of the staging were built and measured slower: the next block column
 // prefetched into registers across the block, and waves 3-7 staging while waves 0-2 substitute -- both push this function
 // past 256 registers, and a spill reload in the MFMA loop waits for every outstanding load.)
+// dm_, mu_ (optional): mu[i] += sum_j X[j][i] dm[j] from the solved tiles while they are still in registers -- the smoother's mean
+// update mu_f + G (mu_s - mu-) with X = G^T (standard.py:213-214) without reading G^T back from memory: per tile the four row
+// terms of a lane, a shuffle sum over the tile's row quarters, the ten row blocks' partial sums through LDS in a fixed order.
 template <bool LOWER>
 __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int trans_, double* Bm_, int ldb_, int n_, int nr_,
-                                               double* ws_end_) {
+                                               double* ws_end_, const double* dm_, double* mu_) {
     auto* const T = uni_g(T_);
     auto* const Bm = uni_g(Bm_);
+    auto* const dmv = uni_g(dm_);
+    auto* const mu = uni_g(mu_);
     auto* const ws_end = uni_g(ws_end_);
     (void)ws_end;
     RK_STAMP_DECL(ws_end);
@@ -547,6 +552,31 @@ __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int t
         }
     }
     __syncthreads();
+    if (mu) {
+        double* const part = g_lds;                                 // [row block][column]: BS_T x (16 BS_T) doubles
+#pragma unroll
+        for (int q = 0; q < BS_Q; ++q) {
+            const int e = wave + NWAVE * q, rb = e / BS_T, ct = e - rb * BS_T;
+            if (e < BS_T * BS_T) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * rb + 4 * v + hi;
+                    sacc = fma(t[q][v], row < n ? dmv[row] : 0.0, sacc);      // (rows past the end hold copies: zero weight)
+                }
+                sacc += __shfl_xor(sacc, 16, 64);
+                sacc += __shfl_xor(sacc, 32, 64);
+                if (hi == 0) part[rb * (16 * BS_T) + 16 * ct + lo] = sacc;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr; i += DT) {
+            double sacc = 0.0;
+            for (int rb = 0; rb < nbk; ++rb) sacc += part[rb * (16 * BS_T) + i];
+            mu[i] = mu[i] + sacc;
+        }
+        __syncthreads();
+    }
     RK_STAMP(10);
 }
 
@@ -573,7 +603,7 @@ __device__ __noinline__ void wg_tri_solve_slow(const double* T_, int ldt_, int t
 template <bool LOWER>
 __device__ __forceinline__ void wg_tri_solve(const double* T, int ldt, int trans, double* Bm, int ldb, int n, int nr,
                                              double* ws_end = nullptr) {
-    if (n <= 16 * BS_T && nr <= 16 * BS_T) wg_tri_solve_regs<LOWER>(T, ldt, trans, Bm, ldb, n, nr, ws_end);
+    if (n <= 16 * BS_T && nr <= 16 * BS_T) wg_tri_solve_regs<LOWER>(T, ldt, trans, Bm, ldb, n, nr, ws_end, nullptr, nullptr);
     else wg_tri_solve_slow<LOWER>(T, ldt, trans, Bm, ldb, n, nr);
 }
 
