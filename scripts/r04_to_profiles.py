@@ -131,8 +131,7 @@ for key, d in (("standard, panel loop over memory (default)", "c5"), ("standard,
                                       "MB_per_trajectory_step_fetch_uncorrected": (f_ + w_) * 1024 / (256 * 50) / 1e6}
 if forms:
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 scripts/bench_configs.py c5 --c5-steps 50 "
-                       "[--c5-kalman square-root], B = 256, p = 160, m = 32; sums over the run's launches of each kernel (warm-up + timed: "
-                       "bench_configs launches the solve twice, so per trajectory-step = bytes / (2 x 256 x 50) -- see 'launches'); counter "
+                       "[--c5-kalman square-root], B = 256, p = 160, m = 32; one launch of each kernel per run (per trajectory-step = bytes / (256 x 50)); counter "
                        "unit KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md.  Algorithmic bytes of a trajectory-step: 3 x 206 KB = 0.62 MB.",
                "forms": forms}, open(f"{P}/r04_c5_pmc_traffic_dense{suf}.json", "w"), indent=1)
     print("  ", f"r04_c5_pmc_traffic_dense{suf}.json")
