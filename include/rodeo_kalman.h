@@ -253,6 +253,13 @@ int rk_fenrir_workspace_bytes(const rk_solve_cfg* cfg, size_t* bytes);
 int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
                        int32_t n_obs, int32_t n_bobs, void* workspace);
+/* The same on the records of the blocked-tile forward pass (kalman_type standard, n_bstate 4 .. 8, rk_solve_filter WITHOUT
+ * RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR: out->var_state = the records): predicted moments are re-evaluated, nothing but the
+ * filtered records is read; the result goes to mean_out (N+1, d, p, B) and var_out (N+1, d, p, p, B), batch-minor.
+ * Replaces the same reference lines as rk_fenrir_solve_mv (src/rodeo/inference/fenrir.py:333-457).                        */
+int rk_fenrir_solve_mv_tiles(rk_handle h, const rk_solve_cfg* cfg, const rk_solve_in* in, const rk_solve_out* out,
+                             const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
+                             int32_t n_obs, int32_t n_bobs, void* workspace, double* mean_out, double* var_out);
 
 /* ---- per-step operator boundary -------------------------------------------------------------------------
  * Batched versions of the nine functions of src/rodeo/kalmantv/standard.py (kalman_type = RK_KALMAN_STANDARD)

@@ -96,6 +96,7 @@ SIGNATURES = {
     "rk_fenrir_backward": (C.c_int, [_H, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "rk_fenrir_workspace_bytes": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
     "rk_fenrir_solve_mv": (C.c_int, [_H, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "rk_fenrir_solve_mv_tiles": (C.c_int, [_H, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "rk_kalman_predict_batched": (C.c_int, [_H, C.POINTER(OpCfg)] + [_P] * 7),
     "rk_kalman_update_batched": (C.c_int, [_H, C.POINTER(OpCfg)] + [_P] * 8),
     "rk_kalman_filter_batched": (C.c_int, [_H, C.POINTER(OpCfg)] + [_P] * 13),

@@ -877,6 +877,50 @@ int rk_fenrir_workspace_bytes(const rk_solve_cfg* c, size_t* bytes) {
     return RK_OK;
 }
 
+// fenrir's solve_mv on the records of the blocked-tile forward pass (n_bstate 4 .. 8, rk_solve_filter without RK_FLAG_STORE_PRED |
+// RK_FLAG_BATCH_MINOR): out->var_state holds the records [Sigma | mu] per (time, trajectory, block); the backward filter re-evaluates
+// the predicted moments from them (fenrir_bwd_kernel<.., STORE, .., TILES>), the smoothing pass writes mean_out (N+1, d, p, B) and
+// var_out (N+1, d, p, p, B), batch-minor.
+int rk_fenrir_solve_mv_tiles(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out,
+                             const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
+                             int32_t n_obs, int32_t n_bobs, void* workspace, double* mean_out, double* var_out) {
+    RK_REQUIRE(h && c && in && out && obs && obs_weight && obs_var && obs_ind && workspace && mean_out && var_out, RK_ERR_INVALID,
+               "rk_fenrir_solve_mv_tiles: null argument");
+    RK_REQUIRE(c->kalman_type == RK_KALMAN_STANDARD && !(c->flags & (RK_FLAG_STORE_PRED | RK_FLAG_BATCH_MINOR)) && c->n_bstate >= 4 &&
+               c->n_bstate <= 8 && (tile4_supported(c, RK_MODE_FILTER) || tilen_supported(c, RK_MODE_FILTER)), RK_ERR_UNSUPPORTED,
+               "rk_fenrir_solve_mv_tiles: a configuration of the blocked-tile forward pass (kalman_type standard, n_bstate 4..8, no "
+               "RK_FLAG_STORE_PRED / RK_FLAG_BATCH_MINOR)");
+    RK_REQUIRE(out->var_state && n_obs >= 0 && n_bobs >= 1 && n_bobs <= 3, RK_ERR_INVALID,
+               "rk_fenrir_solve_mv_tiles: out->var_state (tile records) is null, or n_bobs outside 1..3");
+    SolveArgs a;
+    int rc = make_args(c, in, out, a);
+    if (rc) return rc;
+    a.mean = mean_out; a.var = var_out;                             // (the smoothing pass's output; the backward filter reads the records)
+    RK_HIP(hipSetDevice(h->device));
+    const dim3 grid(div_up(a.B * a.D, 64)), block(64);
+    double* st = (double*)workspace;
+    {
+        LaunchTimer t(h, "fenrir_bwd_kernel<tiles>");
+#define RK_FT(P_, M_) if (c->n_bstate == P_ && n_bobs == M_) hipLaunchKernelGGL((fenrir_bwd_kernel<P_, true, M_, true>), grid, block, 0, h->stream, a, obs, obs_weight, obs_var, obs_ind, n_obs, (double*)nullptr, st, (const double*)out->var_state);
+        RK_FT(4, 1) RK_FT(4, 2) RK_FT(4, 3) RK_FT(5, 1) RK_FT(5, 2) RK_FT(5, 3) RK_FT(6, 1) RK_FT(6, 2) RK_FT(6, 3)
+        RK_FT(7, 1) RK_FT(7, 2) RK_FT(7, 3) RK_FT(8, 1) RK_FT(8, 2) RK_FT(8, 3)
+#undef RK_FT
+        t.stop();
+    }
+    RK_HIP(hipGetLastError());
+    LaunchTimer t(h, "fenrir_smooth_kernel");
+    switch (c->n_bstate) {
+        case 4: hipLaunchKernelGGL(fenrir_smooth_kernel<4>, grid, block, 0, h->stream, a, st); break;
+        case 5: hipLaunchKernelGGL(fenrir_smooth_kernel<5>, grid, block, 0, h->stream, a, st); break;
+        case 6: hipLaunchKernelGGL(fenrir_smooth_kernel<6>, grid, block, 0, h->stream, a, st); break;
+        case 7: hipLaunchKernelGGL(fenrir_smooth_kernel<7>, grid, block, 0, h->stream, a, st); break;
+        default: hipLaunchKernelGGL(fenrir_smooth_kernel<8>, grid, block, 0, h->stream, a, st); break;
+    }
+    t.stop();
+    RK_HIP(hipGetLastError());
+    return RK_OK;
+}
+
 int rk_fenrir_solve_mv(rk_handle h, const rk_solve_cfg* c, const rk_solve_in* in, const rk_solve_out* out,
                        const double* obs, const double* obs_weight, const double* obs_var, const int32_t* obs_ind,
                        int32_t n_obs, int32_t n_bobs, void* workspace) {

@@ -103,6 +103,14 @@ def solve_mv(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrog
         raise ValueError("obs_times must be ascending")
     from ..solve import SolvePlan
     sq = kalman_type == "square-root"                               # (its forward pass is batch-minor and keeps no predictions)
+    if not sq:
+        # n_bstate = 4 .. 8: forward pass on the blocked MFMA tiles, backward filter and smoothing pass on its records
+        # (rk_fenrir_solve_mv_tiles: no stored predictions, no batch-minor copy of the filter's output)
+        tplan = cached_plan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type, **params)
+        lay = C.c_int32(0)
+        _lib.check(tplan.dev.lib.rk_solve_layout(C.byref(tplan.cfg), _lib.MODE_FILTER, C.byref(lay)))
+        if lay.value in (_lib.LAYOUT_TILE4, _lib.LAYOUT_TILEP) and 4 <= tplan.p <= 8:
+            return _solve_mv_tiles(tplan, key, obs, D, Om, ind, n_bobs)
     plan = SolvePlan(ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrogate, prior_pars, kalman_type,
                      store_pred=not sq, batch_minor=not sq, **params)
     if D.shape[1:] != (plan.d, n_bobs, plan.p):
@@ -117,3 +125,20 @@ def solve_mv(key, ode_fun, ode_weight, ode_init, t_min, t_max, n_steps, interrog
                                           d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), n_bobs, ws.ptr))
     return plan.state_host()
 
+
+def _solve_mv_tiles(plan, key, obs, D, Om, ind, n_bobs):
+    """``solve_mv`` on a plan whose forward pass runs on the blocked tiles (n_bstate 4 .. 8)."""
+    if D.shape[1:] != (plan.d, n_bobs, plan.p):
+        raise ValueError(f"obs_weight must have shape (n_obs, {plan.d}, n_bobs, {plan.p})")
+    plan.filter(key)
+    dev = plan.dev
+    d_obs, d_w, d_v, d_ind = (dev.to_device(np.ascontiguousarray(a)) for a in (obs, D, Om, ind.astype(np.int32)))
+    nbytes = C.c_size_t(0)
+    _lib.check(dev.lib.rk_fenrir_workspace_bytes(C.byref(plan.cfg), C.byref(nbytes)))
+    ws = dev.empty((nbytes.value // 8,))
+    N, d, p, B = plan.cfg.n_steps, plan.d, plan.p, plan.cfg.n_traj
+    mean, var = dev.empty((N + 1, d, p, B)), dev.empty((N + 1, d, p, p, B))
+    _lib.check(dev.lib.rk_fenrir_solve_mv_tiles(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(plan._out), d_obs.ptr,
+                                                d_w.ptr, d_v.ptr, d_ind.ptr, int(ind.shape[0]), n_bobs, ws.ptr, mean.ptr, var.ptr))
+    m, v = mean.batch_first(), var.batch_first()
+    return (m, v) if plan.batched else (m[0], v[0])

@@ -530,3 +530,62 @@ def test_fenrir_solve_mv_square_root(ra, p, n_bobs):
         vo, v = Lo @ np.swapaxes(Lo, -1, -2), L[b] @ np.swapaxes(L[b], -1, -2)
         dv = np.sqrt(np.abs(np.einsum("nkii->nki", vo)).max(axis=(0, 1)))
         assert np.max(np.abs(v - vo) / (dv[:, None] * dv[None, :])) < 1e-6
+
+
+@pytest.mark.parametrize("p", [4, 5, 6])          # (n_bstate = 7 on this grid: the fp64 ORACLE meets a singular matrix in its smoothing pass)
+def test_fenrir_solve_mv_on_tile_records(ra, p):
+    """fenrir.solve_mv at n_bstate = 4 .. 8 (fenrir.py:333-457): forward pass on the blocked MFMA tiles, backward filter and
+    smoothing pass on its records (rk_fenrir_solve_mv_tiles: predictions re-evaluated, no lane-per-trajectory filter, no stored
+    predictions) -- against the oracle, and against the lane-per-trajectory path of rk_fenrir_solve_mv where that exists (p <= 6)."""
+    from oracle import fenrir as ofen
+    from rodeo_amd.inference.fenrir import solve_mv as fsolve
+    from rodeo_amd.solve import SolvePlan
+    from rodeo_amd import _lib
+    import ctypes as C
+    N, t_max, B = 80, 4.0, 5
+    rng = np.random.default_rng(40 + p)
+    theta = np.array([0.2, 0.2, 3.0]) * np.exp(0.05 * rng.standard_normal((B, 3)))
+    W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
+    x0 = init(np.array([-1., 1.]) + 0.05 * rng.standard_normal((B, 2)), 0.0, theta=theta)
+    prior = ra.ibm_init(t_max / N, p, np.array([.1, .1]))
+    obs_times = np.array([0.0, 1.0, 2.0, 3.0, 4.0])
+    n_obs = len(obs_times)
+    y = np.array([-1., 1.])[None, :, None] + 0.3 * rng.standard_normal((n_obs, 2, 1))
+    Dw = np.zeros((n_obs, 2, 1, p)); Dw[..., 0] = 1.0
+    Om = np.full((n_obs, 2, 1, 1), 0.02)
+    args = (W, x0, 0.0, t_max, N)
+    g = ra.interrogate.interrogate_kramer
+    dev = ra.device.default_device()
+    dev.profile_enable(True)
+    m, v = fsolve(None, ra.ode.fitzhugh_nagumo, *args, g, prior, y, obs_times, Dw, Om, theta=theta)
+    names = [k for k, _ in dev.profile_last()]
+    dev.profile_enable(False)
+    assert any(k.startswith("fwd_tile") for k in names) and "fenrir_bwd_kernel<tiles>" in names and "fenrir_smooth_kernel" in names, names
+    assert not any(k == "fwd_kernel" for k in names), names
+    assert m.shape == (B, N + 1, 2, p) and v.shape == (B, N + 1, 2, p, p)
+    tol_m, tol_v = {4: (1e-8, 1e-7), 5: (1e-7, 1e-6), 6: (1e-6, 1e-5)}[p]                       # (conditioning, test_gpu_tilen.py)
+    for b in (0, B - 1):
+        mo, vo = ofen.solve_mv(None, odes.fitzhugh_nagumo, W, x0[b], 0.0, t_max, N, oi.interrogate_kramer, prior, y,
+                               obs_times, Dw, Om, theta=theta[b])
+        scale = np.maximum(np.max(np.abs(mo), axis=(0, 1)), 1.0)
+        assert np.max(np.abs(m[b] - mo) / scale) < tol_m
+        assert np.max(np.abs(v[b] - vo)) < tol_v * np.max(np.abs(vo))
+    m1, _ = fsolve(None, ra.ode.fitzhugh_nagumo, W, x0[0], 0.0, t_max, N, g, prior, y, obs_times, Dw, Om, theta=theta[0])
+    assert m1.shape == (N + 1, 2, p) and np.max(np.abs(m1 - m[0])) < 1e-12
+    if p <= 6:
+        # the lane-per-trajectory path (stored predictions) on the same problem
+        from rodeo_amd.inference.fenrir import _check_obs
+        from rodeo_amd.inference.logpost import obs_index
+        obs, D, Omc, n_bobs = _check_obs(y, Dw, Om)
+        ind = obs_index(0.0, t_max, N, obs_times)
+        plan = SolvePlan(ra.ode.fitzhugh_nagumo, *args, g, prior, "standard", store_pred=True, batch_minor=True, theta=theta)
+        plan.filter(None)
+        d_obs, d_w, d_v, d_ind = (dev.to_device(np.ascontiguousarray(a)) for a in (obs, D, Omc, ind.astype(np.int32)))
+        nbytes = C.c_size_t(0)
+        _lib.check(dev.lib.rk_fenrir_workspace_bytes(C.byref(plan.cfg), C.byref(nbytes)))
+        ws = dev.empty((nbytes.value // 8,))
+        _lib.check(dev.lib.rk_fenrir_solve_mv(dev.h, C.byref(plan.cfg), C.byref(plan.inp), C.byref(plan._out), d_obs.ptr, d_w.ptr,
+                                              d_v.ptr, d_ind.ptr, int(ind.shape[0]), n_bobs, ws.ptr))
+        ml, vl = plan.state_host()
+        scale = np.maximum(np.max(np.abs(ml), axis=(0, 1, 2)), 1.0)
+        assert np.max(np.abs(m - ml) / scale) < 10 * tol_m
