@@ -203,7 +203,10 @@ __global__ void __launch_bounds__(64 * TileWaves<RHS::D>::value) fwd_tile3_kerne
         // (interrogate_chkrebtii's gain sequence does not depend on the mean; hand-off of Sigma- W^T, S, Sigma-_00 through LDS,
         // square roots and reciprocals of a chunk taken off the chain) with and without a third generator wave: each chain
         // alone steps in ~270 cycles -- the MFMA dependency chain U -> M-^T -> Sigma- W^T -> S plus the reciprocal is the
-        // kramer step's -- and two chains meet on a SIMD: 156-183 us.  Kept: the one-correction square root below.
+        // kramer step's -- and two chains meet on a SIMD: 156-183 us; (iii) the generator as a resumable computation (normal_pair cut
+        // into 13 pieces, one per step, for the draws of the NEXT 16 steps, two z buffers): 141 -> 138 us -- a VALU instruction behind
+        // an fp64 MFMA waits for it (probe3), so the pieces have no shadow to go into and cost their own issue time wherever they
+        // stand; not worth its second code path.  Kept: the one-correction square root below.
         double tk[6];
         RHS::tile_consts(blk, th, tk);
         const double ac3 = -tk[1], ac1 = -tk[0], aco = -tk[2], ac0 = -tk[3];      // a = -f as the cubic of the generic path's row 3
