@@ -240,8 +240,8 @@ size_t fenrir_sqrt_item_doubles(int p) { return 4 * (size_t)p * p + 2 * (size_t)
 // states == nullptr: the log-density only (rk_fenrir_backward); else the stored backward filter + the smoothing sweep
 int fenrir_sqrt_launch(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, const double* obs, const double* obs_w,
                        const double* obs_v, const int32_t* obs_ind, int n_obs, int n_bobs, double* logdens, double* states) {
-    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 6 && n_bobs >= 1 && n_bobs <= 3, RK_ERR_UNSUPPORTED,
-               "fenrir, kalman_type=square-root: n_bstate in 2..6, n_bobs in 1..3 (got %d, %d)", c->n_bstate, n_bobs);
+    RK_REQUIRE(c->n_bstate >= 2 && c->n_bstate <= 8 && n_bobs >= 1 && n_bobs <= 3, RK_ERR_UNSUPPORTED,
+               "fenrir, kalman_type=square-root: n_bstate in 2..8, n_bobs in 1..3 (got %d, %d)", c->n_bstate, n_bobs);
     const dim3 grid(div_up(a.B * a.D, 64)), block(64);
     {
         LaunchTimer t(h, "fenrir_bwd_sqrt_kernel");
@@ -252,6 +252,7 @@ int fenrir_sqrt_launch(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, c
     }
         RK_FS(2, 1) RK_FS(2, 2) RK_FS(2, 3) RK_FS(3, 1) RK_FS(3, 2) RK_FS(3, 3) RK_FS(4, 1) RK_FS(4, 2) RK_FS(4, 3)
         RK_FS(5, 1) RK_FS(5, 2) RK_FS(5, 3) RK_FS(6, 1) RK_FS(6, 2) RK_FS(6, 3)
+        RK_FS(7, 1) RK_FS(7, 2) RK_FS(7, 3) RK_FS(8, 1) RK_FS(8, 2) RK_FS(8, 3)        // (functional: the stacks spill from n_bstate = 7 on)
 #undef RK_FS
         t.stop();
     }
@@ -263,7 +264,9 @@ int fenrir_sqrt_launch(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, c
         case 3: hipLaunchKernelGGL(fenrir_smooth_sqrt_kernel<3>, grid, block, 0, h->stream, a, states); break;
         case 4: hipLaunchKernelGGL(fenrir_smooth_sqrt_kernel<4>, grid, block, 0, h->stream, a, states); break;
         case 5: hipLaunchKernelGGL(fenrir_smooth_sqrt_kernel<5>, grid, block, 0, h->stream, a, states); break;
-        default: hipLaunchKernelGGL(fenrir_smooth_sqrt_kernel<6>, grid, block, 0, h->stream, a, states); break;
+        case 6: hipLaunchKernelGGL(fenrir_smooth_sqrt_kernel<6>, grid, block, 0, h->stream, a, states); break;
+        case 7: hipLaunchKernelGGL(fenrir_smooth_sqrt_kernel<7>, grid, block, 0, h->stream, a, states); break;
+        default: hipLaunchKernelGGL(fenrir_smooth_sqrt_kernel<8>, grid, block, 0, h->stream, a, states); break;
     }
     t.stop();
     RK_HIP(hipGetLastError());

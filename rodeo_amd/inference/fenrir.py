@@ -13,7 +13,7 @@ vector observations run on the lane-per-trajectory kernels (LU update, eigendeco
 ``kalman_type="square-root"`` (fenrir.py:292-296, 421-426): ``prior_pars[1]`` and ``obs_var`` are lower factors, the forward
 pass is the square-root filter and every backward step map comes from ``square_root.py``; its ``forecast`` squares the
 factor before the log-density sees it (square_root.py:343-344), so the value is the same log-likelihood as in covariance
-form for ``L L^T`` inputs (tests).  Lane-per-trajectory kernels (``fenrir_sqrt.hip``), n_bstate 2 .. 6.
+form for ``L L^T`` inputs (tests).  Lane-per-trajectory kernels (``fenrir_sqrt.hip``), n_bstate 2 .. 8.
 """
 import ctypes as C
 import numpy as np

@@ -462,7 +462,7 @@ def test_fenrir_vector_observations(ra, p, n_bobs):
 
 
 @pytest.mark.parametrize("name,p,n_bobs", [("kramer", 3, 1), ("rodeo", 3, 1), ("kramer", 4, 1), ("kramer", 3, 2), ("rodeo", 5, 2),
-                                            ("kramer", 2, 1), ("kramer", 6, 3)])
+                                            ("kramer", 2, 1), ("kramer", 6, 3), ("kramer", 7, 1), ("rodeo", 8, 2)])
 def test_fenrir_parity_square_root(ra, name, p, n_bobs):
     """fenrir with kalman_type="square-root" (src/rodeo/inference/fenrir.py:292-296 with square_root.py:30-345: the forecast
     returns the full variance, square_root.py:343-344): prior_pars[1] and obs_var are lower factors.  Device against the
@@ -475,7 +475,10 @@ def test_fenrir_parity_square_root(ra, name, p, n_bobs):
     W, init = ra.utils.first_order_pad(ra.ode.fitzhugh_nagumo, 2, p)
     x0 = init(np.array([-1., 1.]) + 0.05 * rng.standard_normal((B, 2)), 0.0, theta=theta)
     Q, R = ra.ibm_init(t_max / N, p, np.array([.1, .1]))
-    Rh = np.linalg.cholesky(R)
+    if p >= 7:                                           # (the IBM variance matrix is singular in fp64 there: a well-conditioned factor)
+        Rh = np.tril(0.02 * rng.standard_normal((2, p, p))) + np.eye(p) * 0.1
+    else:
+        Rh = np.linalg.cholesky(R)
     obs_times = np.array([0.0, 0.75, 1.5, 2.2, 3.0])
     n_obs = len(obs_times)
     y = rng.standard_normal((n_obs, 2, n_bobs))
@@ -489,7 +492,7 @@ def test_fenrir_parity_square_root(ra, name, p, n_bobs):
                               theta=theta)
     ref = ofen.fenrir(None, odes.fitzhugh_nagumo, *args, o, (Q, Rh), y, obs_times, Dw, Oh, kalman_type="square-root", theta=theta)
     assert val.shape == (B,)
-    tol = 1e-7 if p <= 4 else 1e-5
+    tol = 1e-7 if p <= 4 else (1e-5 if p <= 6 else 1e-4)
     np.testing.assert_allclose(val, ref, rtol=tol, atol=tol)
     if name == "kramer" and p <= 4:
         std = ra.inference.fenrir(None, ra.ode.fitzhugh_nagumo, *args, g, (Q, R), y, obs_times, Dw, Om, theta=theta)
