@@ -22,7 +22,7 @@ def _run(*args, timeout=600):
     return json.loads(lines[0])
 
 
-def _common(d, n_gpus, steps, warmup):
+def _common(d, n_gpus, steps, warmup, shared_gpu=False):
     assert d["unit"] == "trajectory-steps/s" and "FitzHugh-Nagumo" in d["metric"] and "4000 steps" in d["metric"]
     assert d["n_gpus"] == n_gpus and d["steps"] == steps and d["warmup"] == warmup
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -32,7 +32,8 @@ def _common(d, n_gpus, steps, warmup):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["kernel"] in d["kernels_ms"] and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or 0.9 < r["traffic"] / (r["algorithmic_bytes_per_traj_step"] * 1024 * 4000) < 1.5
-    assert 0.2 < d["roofline_solve"]["frac"] < 1.0
+    # (two ranks rehearsing on ONE card halve each rank's rate: ~0.21 nominal, seen between 0.18 and 0.22)
+    assert (0.1 if shared_gpu else 0.2) < d["roofline_solve"]["frac"] < 1.0
     # the per-kernel times come from the timed solves themselves and add up to (a bit less than) the wall time per solve
     assert 0.8 * d["ms_per_step"] < sum(d["kernels_ms"].values()) <= 1.02 * d["ms_per_step"]
 
@@ -48,5 +49,5 @@ def test_single_process_line_with_cpu_baseline():
 
 def test_two_ranks_on_one_gpu_fall_back_to_the_host_channel():
     d = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
-    _common(d, 2, 3, 1)
+    _common(d, 2, 3, 1, shared_gpu=True)
     assert d["config"]["comm"] in ("host-tcp", "rccl") and "cpu_baseline" not in d
