@@ -307,6 +307,23 @@ __device__ __forceinline__ void wg_gemm_dma_body(gd* C, int ldc, cgd* A, int lda
             d4 acc[G_TPW];
 #pragma unroll
             for (int q = 0; q < G_TPW; ++q) acc[q] = d4{0, 0, 0, 0};
+            // C = E +- A B (ce = 1, |cab| = 1: the smoother's Sigma_f + (G D) G^T, the filter's Sigma- - K (W~ Sigma-)): E goes into the
+            // accumulators up front, its loads under the first chunk's DMA, instead of 13 load -> store round trips per wave at the
+            // end (C may be E: no load of the next tile can pass a store of this one -- 43 k cycles of (GD)G^T against G D).  The sum
+            // then runs E + a1 b1 + a2 b2 ... instead of E + (a1 b1 + ...): another rounding order, same terms.
+            const bool pre = E != nullptr && ce == 1.0 && (cab == 1.0 || cab == -1.0);
+            if (pre) {
+#pragma unroll
+                for (int q = 0; q < G_TPW; ++q) {
+                    const int e = wave + NWAVE * q;
+                    if (e < T) {
+                        const int ti = e / nt, tj = e - ti * nt;
+                        const int j = min(j0 + 16 * tj + lo, N - 1);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[q][v] = cab * E[min(i0 + 16 * ti + 4 * v + hi, M - 1) * lde + j];     // (clamped, unmasked)
+                    }
+                }
+            }
             auto issue = [&](int k0, int buf) {
                 gd_issue<AKM>(lds + buf * GD_BUF, A, lda, k0, i0, mb, wave, lane);
                 gd_issue<BKM>(lds + (2 + buf) * GD_BUF, B, ldb, k0, j0, nbk, wave, lane);
@@ -348,12 +365,12 @@ __device__ __forceinline__ void wg_gemm_dma_body(gd* C, int ldc, cgd* A, int lda
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int ii = i0 + 16 * ti + 4 * v + hi;
-                        ev[v] = (E && ii < M && j < N) ? E[ii * lde + j] : 0.0;
+                        ev[v] = (E && !pre && ii < M && j < N) ? E[ii * lde + j] : 0.0;
                     }
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int ii = i0 + 16 * ti + 4 * v + hi;
-                        if (ii < M && j < N) C[ii * ldc + j] = fma(ce, ev[v], cab * acc[q][v]);
+                        if (ii < M && j < N) C[ii * ldc + j] = pre ? cab * acc[q][v] : fma(ce, ev[v], cab * acc[q][v]);
                     }
                 }
             }
