@@ -497,15 +497,36 @@ __device__ __noinline__ void wg_tri_solve_regs(const double* T_, int ldt_, int t
         const int k0 = 16 * k, nb = min(16, n - k0);
         const int r_lo = LOWER ? k0 : 0, nrow = LOWER ? n - k0 : k0 + nb;
         __syncthreads();                                            // the previous block's panel and scratches are free
-        if (!trans) {
-            for (int e = threadIdx.x; e < nrow * LU_NB; e += DT) {
-                const int r = r_lo + (e >> 4), c = e & 15;
-                panel[r * LU_LD + c] = c < nb ? T[r * ldt + k0 + c] : 0.0;
-            }
-        } else {
-            for (int e = threadIdx.x; e < nrow * LU_NB; e += DT) {
-                const int c = e / nrow, r = r_lo + (e - c * nrow);
-                panel[r * LU_LD + c] = c < nb ? T[(k0 + c) * ldt + r] : 0.0;
+        // (all loads of the block column first, clamped instead of masked, then the LDS writes: the rolled loop had ONE load in flight
+        //  per thread -- up to five global round trips per block, 71 k of the substitution's 195 k cycles at n = 160)
+        {
+            constexpr int SU = (16 * BS_T * LU_NB + DT - 1) / DT;   // elements per thread at the largest block column
+            const int total = nrow * LU_NB;
+            double sv[SU];
+            if (!trans) {
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int e = min((int)threadIdx.x + DT * u, total - 1);
+                    sv[u] = T[(r_lo + (e >> 4)) * ldt + k0 + min(e & 15, nb - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int e = threadIdx.x + DT * u;
+                    if (e < total) panel[(r_lo + (e >> 4)) * LU_LD + (e & 15)] = (e & 15) < nb ? sv[u] : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int e = min((int)threadIdx.x + DT * u, total - 1);
+                    const int c = e / nrow, r = r_lo + (e - c * nrow);
+                    sv[u] = T[(k0 + min(c, nb - 1)) * ldt + r];
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int e = threadIdx.x + DT * u;
+                    const int c = e / nrow, r = r_lo + (e - c * nrow);
+                    if (e < total) panel[r * LU_LD + c] = c < nb ? sv[u] : 0.0;
+                }
             }
         }
 #pragma unroll
