@@ -1415,18 +1415,8 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
                     // interrogate.py:81-82) in w.f.  Built in: the linear ODE f = A x, x_v = X[v * nd]; a right-hand
                     // side that arrives through hiprtc has filled both from its own kernel between two launches of this
                     // one (MODE != 0, solve_dense_itg_kernels.hpp) ----
-                    if (MODE == 0) {
-                        for (int e = threadIdx.x; e < m * p; e += DT) {
-                            const int i = e / p, j = e % p;
-                            double Jij = 0.0;
-                            if (a.itg == RK_INTERROGATE_KRAMER && j % nd == 0) {
-                                const int v = j / nd;
-                                Jij = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
-                            }
-                            w.Wt[e] = a.W[e] + (-Jij);                                   // W + wgt_meas   (solve.py:79)
-                        }
-                        __syncthreads();
-                    }
+                    // (MODE 0: W~ of the built-in linear ODE does not change with the step -- built once in front of the time loop)
+                    if (MODE == 0) __syncthreads();                                       // mu- of phase 2 is complete
                     // yhat = W~ mu- + a (standard.py:93); for the linear ODE f_i = sum_v A_iv x_v and J mu- = (W - W~) mu-:
                     // one wave per measurement row, lanes along the sums, wave reduction
                     for (int i = threadIdx.x >> 6; i < m; i += DT / 64) {
@@ -1478,6 +1468,17 @@ __global__ void __launch_bounds__(DT) dense_fwd_kernel(DenseArgs a) {
     using P3 = std::integral_constant<int, 3>;
     using P7 = std::integral_constant<int, 7>;
     if (MODE == 0) {
+        // W~ = W - J (solve.py:79) for the built-in linear ODE f = A x: J = A (kramer) or 0, the same at every step and every state
+        for (int e = threadIdx.x; e < m * p; e += DT) {
+            const int i = e / p, j = e % p;
+            double Jij = 0.0;
+            if (a.itg == RK_INTERROGATE_KRAMER && j % nd == 0) {
+                const int v = j / nd;
+                Jij = a.theta_b ? Aode[((size_t)i * m + v) * a.B + b] : Aode[(size_t)i * m + v];
+            }
+            w.Wt[e] = a.W[e] + (-Jij);                                               // W + wgt_meas   (solve.py:79)
+        }
+        __syncthreads();
         for (int n = 0; n < a.N; ++n) phases(n, P0{}, P7{});
     } else if (MODE == 1) {
         phases(0, P0{}, P3{});
