@@ -378,6 +378,10 @@ __device__ __forceinline__ void wg_gemm_dma_body(gd* C, int ldc, cgd* A, int lda
     __syncthreads();
 }
 
+// (Round 4: a barrier-free path for the SKINNY products of the filter step -- M = n_bmeas = 32 rows, a wave owning whole column tiles and
+//  feeding its MFMAs straight from memory, 60 fragment loads in flight per lane -- was measured slower than the chunked path it was
+//  meant to replace: W~ Sigma- 75 k -> 107 k cycles, (Sigma- W~^T)^T 47 k -> 97 k: 8-byte fragment loads spread over 16 rows per
+//  instruction cost the address path more than the ten barriers and round trips they avoid.)
 __device__ __noinline__ void wg_gemm(const GemmOp& g_) {
     const GemmOp& gr = *uni(&g_);
     const int K = uni(gr.K), lda = uni(gr.lda), ldb = uni(gr.ldb);
