@@ -328,6 +328,11 @@ __device__ __forceinline__ void wg_gemm_dma_body(gd* C, int ldc, cgd* A, int lda
                 gd_issue<AKM>(lds + buf * GD_BUF, A, lda, k0, i0, mb, wave, lane);
                 gd_issue<BKM>(lds + (2 + buf) * GD_BUF, B, ldb, k0, j0, nbk, wave, lane);
             };
+            // (Round 4: THREE buffers per operand with counted waits -- s_waitcnt vmcnt(this wave's DMAs per chunk) + an LDS-only barrier, so
+            //  that chunk c + 2 is in flight while chunk c is multiplied -- changed nothing: G D 141 k, (GD)G^T 168 k cycles as before.  A
+            //  chunk of the 160 x 160 products is 52 MFMAs per wave = 6.7 k cycles of the SIMD's matrix pipe for its two waves (probe14:
+            //  7.5 k with the LDS reads) against a ~5 k round trip that two buffers already hide; what is left over the 64 k of the
+            //  MFMAs alone is the barrier per chunk, LDS reads that do not overlap MFMAs, and the first and last chunk.)
             __syncthreads();                                        // whoever used the LDS before is done with it
             issue(0, 0);
             for (int k0 = 0, buf = 0; k0 < K; k0 += GD_KC, buf ^= 1) {
