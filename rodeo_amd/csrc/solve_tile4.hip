@@ -523,7 +523,8 @@ int tile4_solve(rk_handle h, const rk_solve_cfg* c, const SolveArgs& a, double* 
     // confirm the placement, and the consumer's tick stayed at 3925 cycles against 3945, 245 per step, even with ONE set per CU,
     // profiles/r04_c3_dedicated_simd.txt).  What shortened the step was the dense image (one ds_write2_b64 per step: 245 -> 190 cycles);
     // with it the three-tile shape runs 2.22 ms in ds against 2.79 in quad (C3), the four-tile shape 0.57 in quad against 0.68 in ds
-    // (FitzHugh-Nagumo, n_deriv 4): the default follows the shape.
+    // (FitzHugh-Nagumo, n_deriv 4): the default follows the shape.  (A third producer per set on waves 4, 5 of the two-set layout: 2.30-2.32
+    // against 2.29 ms -- at 4.3 TB/s of reads and writes in equal parts the pass is at the rate the memory system gives this stream.)
     static const int forced = [] { const char* e = getenv("RK_T4_BWD"); return e && e[0] == 'd' ? 2 : (e && e[0] == 'q' ? 1 : 0); }();
     const bool quad = forced ? forced == 1 : tpw != 3;
     const int n_tw = div_up(a.B * a.D, tpw);
