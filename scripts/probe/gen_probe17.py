@@ -20,6 +20,13 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 # V0: hipcc's own order of the shipped kernel (from the assembly), V1: the source order of the shipped kernel
 orders = [["U", "VO", "SPT", "SP", "DPP", "AM", "Z", "MP", "WS", "SC", "YH", "RCP", "E", "Y", "K", "SN", "MN"],
           ["U", "VO", "MP", "SPT", "SP", "DPP", "AM", "Z", "WS", "YH", "SC", "RCP", "E", "Y", "K", "SN", "MN"]]
+# hand-made orders by the "a VALU instruction behind an MFMA waits for it" model: few groups of back-to-back MFMAs
+orders += [["U", "MP", "VO", "DPP", "AM", "SPT", "SP", "Z", "WS", "YH", "SC", "RCP", "E", "Y", "K", "SN", "MN"],
+           ["U", "VO", "MP", "DPP", "AM", "SPT", "SP", "Z", "WS", "YH", "SC", "RCP", "E", "Y", "K", "SN", "MN"],
+           ["U", "VO", "SPT", "MP", "SP", "Z", "DPP", "AM", "WS", "SC", "YH", "RCP", "E", "Y", "K", "SN", "MN"],
+           ["U", "VO", "SPT", "SP", "MP", "Z", "SC", "DPP", "AM", "WS", "YH", "RCP", "E", "Y", "K", "SN", "MN"],
+           ["U", "SPT", "VO", "Z", "MP", "SC", "SP", "DPP", "AM", "WS", "YH", "RCP", "E", "Y", "K", "SN", "MN"],
+           ["U", "SPT", "VO", "Z", "SP", "SC", "MP", "WS", "RCP", "DPP", "AM", "E", "Y", "YH", "K", "SN", "MN"]]
 seen = {tuple(o) for o in orders}
 while len(orders) < count:
     done, o = set(), []
